@@ -1,0 +1,672 @@
+/*
+ * fnft_oracle.c -- CPU restatement (plain C99) of FNFT's fnft_nsev continuous-spectrum path.
+ *
+ * TEST INFRASTRUCTURE ONLY: the checker for the HIP path, never the thing shipped or measured
+ * (except as bench.py's "cpu_baseline" of kind "port").  Parity status: PINNED by the
+ * reference's own known-answer vectors (tests/golden/reference_fixtures.json); see fnft_oracle.h.
+ *
+ * file:line citations are relative to /root/reference.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "fnft_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static const double ORC_PI = 3.14159265358979323846264338327950288;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static double g_timings[2];
+void orc_last_timings(double out[2]) { out[0] = g_timings[0]; out[1] = g_timings[1]; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* FFT: Stockham autosort, mixed radix 4/2/3/5.                                                */
+/* Length policy follows src/3rd_party/kiss_fft/kiss_fft.c:396-408 (smallest 2^a 3^b 5^c >= n); */
+/* transform semantics follow include/private/fnft__fft_wrapper.h:124-137 (out-of-place,      */
+/* sign -1 forward / +1 inverse, no 1/len).  The butterfly schedule is this file's own.        */
+/* ------------------------------------------------------------------------------------------ */
+
+size_t orc_next_fast_size(size_t n)
+{
+    if (n == 0) return 1;
+    for (;; n++) {
+        size_t m = n;
+        while (m % 2 == 0) m /= 2;
+        while (m % 3 == 0) m /= 3;
+        while (m % 5 == 0) m /= 5;
+        if (m <= 1) return n;
+    }
+}
+
+typedef struct {
+    size_t len;
+    int sign;
+    int nfac;
+    int fac[64];
+    orc_cplx *tw;   /* tw[k] = exp(sign*2*pi*i*k/len), k < len */
+    orc_cplx *work; /* len */
+} orc_plan;
+
+static int plan_init(orc_plan *pl, size_t len, int sign)
+{
+    memset(pl, 0, sizeof(*pl));
+    pl->len = len;
+    pl->sign = sign;
+    size_t m = len;
+    while (m % 4 == 0) { pl->fac[pl->nfac++] = 4; m /= 4; }
+    while (m % 2 == 0) { pl->fac[pl->nfac++] = 2; m /= 2; }
+    while (m % 3 == 0) { pl->fac[pl->nfac++] = 3; m /= 3; }
+    while (m % 5 == 0) { pl->fac[pl->nfac++] = 5; m /= 5; }
+    if (m != 1) return ORC_EC_INVALID_ARGUMENT;
+    pl->tw = malloc(len * sizeof(orc_cplx));
+    pl->work = malloc(len * sizeof(orc_cplx));
+    if (!pl->tw || !pl->work) return ORC_EC_NOMEM;
+    for (size_t k = 0; k < len; k++) {
+        /* reduce the angle through the exact octant symmetries for accuracy */
+        double ang = (double)sign * 2.0 * ORC_PI * (double)k / (double)len;
+        pl->tw[k] = cos(ang) + I * sin(ang);
+    }
+    return ORC_SUCCESS;
+}
+
+static void plan_free(orc_plan *pl)
+{
+    free(pl->tw);
+    free(pl->work);
+    pl->tw = pl->work = NULL;
+}
+
+/* One Stockham decimation-in-frequency pass of radix r on n_cur-point sub-problems:
+ *   y[q + s*(r*p + k)] = w_{n_cur}^{p k} * sum_j x[q + s*(p + m*j)] w_r^{j k},  m = n_cur/r. */
+static void stockham_pass(const orc_plan *pl, size_t n_cur, size_t s, int r,
+                          const orc_cplx *x, orc_cplx *y)
+{
+    const size_t len = pl->len;
+    const size_t m = n_cur / (size_t)r;
+    const size_t tstep = len / n_cur; /* w_{n_cur}^a = tw[a*tstep] */
+    const size_t rstep = len / (size_t)r;
+    const double sg = (double)pl->sign;
+    for (size_t p = 0; p < m; p++) {
+        for (size_t q = 0; q < s; q++) {
+            const orc_cplx *xin = x + q + s * p;
+            orc_cplx *yout = y + q + s * (size_t)r * p;
+            if (r == 2) {
+                orc_cplx a = xin[0], b = xin[s * m];
+                yout[0] = a + b;
+                yout[s] = (a - b) * pl->tw[p * tstep];
+            } else if (r == 4) {
+                orc_cplx a = xin[0], b = xin[s * m], c = xin[2 * s * m], d = xin[3 * s * m];
+                orc_cplx apc = a + c, amc = a - c, bpd = b + d;
+                orc_cplx jbmd = (I * sg) * (b - d); /* w_4^1 = sign*i */
+                yout[0] = apc + bpd;
+                yout[s] = (amc + jbmd) * pl->tw[p * tstep];
+                yout[2 * s] = (apc - bpd) * pl->tw[(2 * p * tstep) % len];
+                yout[3 * s] = (amc - jbmd) * pl->tw[(3 * p * tstep) % len];
+            } else {
+                orc_cplx v[5];
+                for (int j = 0; j < r; j++) v[j] = xin[(size_t)j * s * m];
+                for (int k = 0; k < r; k++) {
+                    orc_cplx acc = v[0];
+                    for (int j = 1; j < r; j++)
+                        acc += v[j] * pl->tw[(((size_t)(j * k) % (size_t)r) * rstep) % len];
+                    yout[(size_t)k * s] = acc * pl->tw[((size_t)k * p * tstep) % len];
+                }
+            }
+        }
+    }
+}
+
+static void plan_exec(orc_plan *pl, const orc_cplx *in, orc_cplx *out)
+{
+    const size_t len = pl->len;
+    if (pl->nfac == 0) { out[0] = in[0]; return; }
+    /* ping-pong between out and work so that the last pass lands in out */
+    orc_cplx *bufs[2];
+    bufs[0] = (pl->nfac % 2 == 1) ? out : pl->work;
+    bufs[1] = (pl->nfac % 2 == 1) ? pl->work : out;
+    const orc_cplx *src = in;
+    size_t n_cur = len, s = 1;
+    for (int f = 0; f < pl->nfac; f++) {
+        orc_cplx *dst = bufs[f % 2];
+        stockham_pass(pl, n_cur, s, pl->fac[f], src, dst);
+        n_cur /= (size_t)pl->fac[f];
+        s *= (size_t)pl->fac[f];
+        src = dst;
+    }
+}
+
+int orc_fft(size_t len, const orc_cplx *in, orc_cplx *out, int sign)
+{
+    orc_plan pl;
+    int rc = plan_init(&pl, len, sign);
+    if (rc == ORC_SUCCESS) plan_exec(&pl, in, out);
+    plan_free(&pl);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* fnft__poly_eval.c:25-53 -- Horner; for |z|>1 the reversed polynomial is evaluated in 1/z. */
+int orc_poly_eval(size_t deg, const orc_cplx *p, size_t nz, orc_cplx *z)
+{
+    if (!p || !z) return ORC_EC_INVALID_ARGUMENT;
+    for (size_t i = 0; i < nz; i++) {
+        orc_cplx acc;
+        if (cabs(z[i]) <= 1.0) {
+            acc = p[0];
+            for (size_t k = 1; k <= deg; k++) acc = p[k] + z[i] * acc;
+        } else {
+            orc_cplx zi = 1.0 / z[i];
+            acc = p[deg];
+            for (size_t k = deg; k-- > 0;) acc = p[k] + zi * acc;
+            acc *= cpow(z[i], (double)deg);
+        }
+        z[i] = acc;
+    }
+    return ORC_SUCCESS;
+}
+
+/* fnft__misc.c:41-51 */
+double orc_rel_err(size_t len, const orc_cplx *numer, const orc_cplx *exact)
+{
+    double n = 0.0, d = 0.0;
+    for (size_t i = 0; i < len; i++) {
+        n += cabs(numer[i] - exact[i]);
+        d += cabs(exact[i]);
+    }
+    return n / d;
+}
+
+/* fnft__misc.c:316-324 */
+size_t orc_nextpowerof2(size_t n)
+{
+    if (n == 0) return 0;
+    size_t r = 1;
+    while (r < n) r *= 2;
+    return r;
+}
+
+/* fnft__misc.c:306-314 */
+static orc_cplx orc_csinc(orc_cplx x)
+{
+    if (cabs(x) >= 1.0e-8) return csin(x) / x;
+    return ccos(x / csqrt(3));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* product tree                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* fnft__poly_fmult.c:40-43 */
+size_t orc_poly_fmult2x2_numel(size_t deg, size_t n) { return 4 * (deg + 1) * orc_nextpowerof2(n); }
+
+/* One 2x2 pair product (fnft__poly_fmult.c:239-328 with 50-121 inlined): every one of the 8
+ * input polynomials is transformed once, the two partial products of each entry are summed in
+ * the frequency domain (the reference's "mode 2/3"), 4 inverse transforms, scaling by 1/len.
+ * The reference's "mode 0/1" (8 inverse transforms, sum in the coefficient domain) differs from
+ * this only by rounding. */
+static void pair_product(size_t deg, const orc_cplx *a11, size_t a_stride, const orc_cplx *b11,
+                         size_t b_stride, orc_cplx *c11, size_t c_stride, orc_plan *fwd,
+                         orc_plan *inv, orc_cplx *spec /* 8*len */, orc_cplx *tmp /* 2*len */)
+{
+    const size_t len = fwd->len;
+    const orc_cplx *src[8] = {a11, a11 + a_stride, a11 + 2 * a_stride, a11 + 3 * a_stride,
+                              b11, b11 + b_stride, b11 + 2 * b_stride, b11 + 3 * b_stride};
+    for (int e = 0; e < 8; e++) {
+        memcpy(tmp, src[e], (deg + 1) * sizeof(orc_cplx));
+        memset(tmp + deg + 1, 0, (len - deg - 1) * sizeof(orc_cplx));
+        plan_exec(fwd, tmp, spec + (size_t)e * len);
+    }
+    const orc_cplx *A11 = spec, *A12 = spec + len, *A21 = spec + 2 * len, *A22 = spec + 3 * len;
+    const orc_cplx *B11 = spec + 4 * len, *B12 = spec + 5 * len, *B21 = spec + 6 * len,
+                   *B22 = spec + 7 * len;
+    const double scl = 1.0 / (double)len;
+    for (int e = 0; e < 4; e++) {
+        const orc_cplx *L1 = (e < 2) ? A11 : A21, *L2 = (e < 2) ? A12 : A22;
+        const orc_cplx *R1 = (e % 2 == 0) ? B11 : B12, *R2 = (e % 2 == 0) ? B21 : B22;
+        for (size_t k = 0; k < len; k++) tmp[k] = L1[k] * R1[k] + L2[k] * R2[k];
+        plan_exec(inv, tmp, tmp + len);
+        orc_cplx *dst = c11 + (size_t)e * c_stride;
+        for (size_t k = 0; k < 2 * deg + 1; k++) dst[k] = tmp[len + k] * scl;
+    }
+}
+
+/* fnft__poly_fmult.c:330-374 */
+static int32_t rescale2x2(size_t d, orc_cplx *c11, orc_cplx *c12, orc_cplx *c21, orc_cplx *c22)
+{
+    double mx = 0.0;
+    for (size_t i = 0; i <= d; i++) {
+        double v;
+        v = cabs(c11[i]); if (v > mx) mx = v;
+        v = cabs(c12[i]); if (v > mx) mx = v;
+        v = cabs(c21[i]); if (v > mx) mx = v;
+        v = cabs(c22[i]); if (v > mx) mx = v;
+    }
+    if (mx == 0.0) return 0;
+    const int32_t a = (int32_t)floor(log2(mx));
+    const double scl = pow(2.0, -a);
+    for (size_t i = 0; i <= d; i++) {
+        c11[i] *= scl; c12[i] *= scl; c21[i] *= scl; c22[i] *= scl;
+    }
+    return a;
+}
+
+/* fnft__poly_fmult.c:381-546 */
+int orc_poly_fmult2x2(size_t *d, size_t n, orc_cplx *p, orc_cplx *result, int32_t *W_ptr)
+{
+    if (!d || !p || !result || n == 0) return ORC_EC_INVALID_ARGUMENT;
+    const size_t deg0 = *d;
+    size_t deg = deg0;
+    const size_t n0 = n;
+    const size_t n_excess = orc_nextpowerof2(n) - n;
+    int32_t W = 0;
+
+    /* :404-445 -- move entries to the padded stride, append n_excess copies of z^deg * I */
+    if (n_excess > 0) {
+        const size_t np = n + n_excess;
+        for (int e = 3; e >= 1; e--)
+            memmove(p + (size_t)e * np * (deg + 1), p + (size_t)e * n * (deg + 1),
+                    n * (deg + 1) * sizeof(orc_cplx));
+        for (int e = 0; e < 4; e++) {
+            orc_cplx *pad = p + (size_t)e * np * (deg + 1) + n * (deg + 1);
+            for (size_t i = 0; i < n_excess * (deg + 1); i++) pad[i] = 0.0;
+            if (e == 0 || e == 3)
+                for (size_t i = 0; i < n_excess; i++) pad[i * (deg + 1)] = 1.0;
+        }
+        n = np;
+    }
+    const size_t p_stride = n * (deg + 1);
+
+    const size_t maxlen = orc_next_fast_size(2 * (deg * n / 2 + 1) - 1);
+    orc_cplx *spec = malloc(8 * maxlen * sizeof(orc_cplx));
+    orc_cplx *tmp = malloc(2 * maxlen * sizeof(orc_cplx));
+    if (!spec || !tmp) { free(spec); free(tmp); return ORC_EC_NOMEM; }
+
+    size_t r_stride = 0;
+    int rc = ORC_SUCCESS;
+    if (n < 2) { /* single matrix: nothing to multiply */
+        for (int e = 0; e < 4; e++)
+            memcpy(result + (size_t)e * (deg + 1), p + (size_t)e * p_stride,
+                   (deg + 1) * sizeof(orc_cplx));
+        r_stride = deg + 1;
+    }
+    while (n >= 2) { /* :460-519 */
+        const size_t len = orc_next_fast_size(2 * (deg + 1) - 1);
+        orc_plan fwd, inv;
+        rc = plan_init(&fwd, len, -1);
+        if (rc == ORC_SUCCESS) rc = plan_init(&inv, len, +1);
+        if (rc != ORC_SUCCESS) { plan_free(&fwd); plan_free(&inv); break; }
+        r_stride = (n / 2) * (2 * deg + 1);
+        for (size_t i = 0; i < n; i += 2) {
+            const size_t o1 = i * (deg + 1), o2 = o1 + (deg + 1), orr = (i / 2) * (2 * deg + 1);
+            pair_product(deg, p + o1, p_stride, p + o2, p_stride, result + orr, r_stride, &fwd,
+                         &inv, spec, tmp);
+            if (W_ptr)
+                W += rescale2x2(2 * deg, result + orr, result + r_stride + orr,
+                                result + 2 * r_stride + orr, result + 3 * r_stride + orr);
+        }
+        plan_free(&fwd);
+        plan_free(&inv);
+        deg *= 2;
+        n /= 2;
+        if (n > 1)
+            for (int e = 0; e < 4; e++)
+                memcpy(p + (size_t)e * p_stride, result + (size_t)e * r_stride,
+                       n * (deg + 1) * sizeof(orc_cplx));
+    }
+    free(spec);
+    free(tmp);
+    if (rc != ORC_SUCCESS) return rc;
+
+    /* :522-533 -- drop the trailing zero coefficients the identity padding produced */
+    if (n_excess > 0 && n0 > 0) {
+        deg -= n_excess * deg0;
+        for (int e = 1; e < 4; e++)
+            memmove(result + (size_t)e * (deg + 1), result + (size_t)e * r_stride,
+                    (deg + 1) * sizeof(orc_cplx));
+    }
+    *d = deg;
+    if (W_ptr) *W_ptr = W;
+    return ORC_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* chirp z-transform, fnft__poly_chirpz.c:33-105                                               */
+/* ------------------------------------------------------------------------------------------ */
+int orc_poly_chirpz(size_t deg, const orc_cplx *p, orc_cplx A, orc_cplx W, size_t M,
+                    orc_cplx *result)
+{
+    if (!p || M == 0 || !result) return ORC_EC_INVALID_ARGUMENT;
+    const size_t N = deg + 1;
+    const size_t L = orc_next_fast_size(N + M - 1);
+    orc_cplx *Y = malloc(L * sizeof(orc_cplx)), *V = malloc(L * sizeof(orc_cplx)),
+             *buf = malloc(L * sizeof(orc_cplx));
+    orc_plan fwd, inv;
+    int rc = (Y && V && buf) ? ORC_SUCCESS : ORC_EC_NOMEM;
+    memset(&fwd, 0, sizeof fwd);
+    memset(&inv, 0, sizeof inv);
+    if (rc == ORC_SUCCESS) rc = plan_init(&fwd, L, -1);
+    if (rc == ORC_SUCCESS) rc = plan_init(&inv, L, +1);
+    if (rc == ORC_SUCCESS) {
+        for (size_t n = 0; n < N; n++) { /* :68-71 */
+            const double dn = (double)n;
+            buf[n] = p[deg - n] * cpow(A, -1.0 * dn) * cpow(W, 0.5 * dn * dn);
+        }
+        for (size_t n = N; n < L; n++) buf[n] = 0;
+        plan_exec(&fwd, buf, Y);
+        for (size_t n = 0; n < M; n++) { /* :76-82 */
+            const double dn = (double)n;
+            buf[n] = cpow(W, -0.5 * dn * dn);
+        }
+        for (size_t n = M; n <= L - N; n++) buf[n] = 0;
+        for (size_t n = L - N + 1; n < L; n++) {
+            const double dn = (double)(L - n);
+            buf[n] = cpow(W, -0.5 * dn * dn);
+        }
+        plan_exec(&fwd, buf, V);
+        for (size_t n = 0; n < L; n++) buf[n] = V[n] * Y[n];
+        plan_exec(&inv, buf, V);
+        for (size_t n = 0; n < M; n++) { /* :94-95 */
+            const double dn = (double)n;
+            result[n] = cpow(W, 0.5 * dn * dn) * V[n] / (double)L;
+        }
+    }
+    plan_free(&fwd);
+    plan_free(&inv);
+    free(Y); free(V); free(buf);
+    return rc;
+}
+
+int orc_poly_chirpz_p(size_t deg, const orc_cplx *p, const double *A, const double *W, size_t M,
+                      orc_cplx *result)
+{
+    return orc_poly_chirpz(deg, p, A[0] + I * A[1], W[0] + I * W[1], M, result);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-sample AKNS coefficients                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* fnft__akns_discretization.c:29-67 (schemes this restatement covers) */
+size_t orc_akns_degree(int disc)
+{
+    switch (disc) {
+    case ORC_AKNS_2SPLIT2_MODAL: case ORC_AKNS_2SPLIT1A: case ORC_AKNS_2SPLIT1B:
+    case ORC_AKNS_2SPLIT2A: case ORC_AKNS_2SPLIT2B: case ORC_AKNS_2SPLIT2S: return 1;
+    case ORC_AKNS_2SPLIT3S: case ORC_AKNS_2SPLIT4B: return 2;
+    case ORC_AKNS_2SPLIT3A: case ORC_AKNS_2SPLIT3B: return 3;
+    case ORC_AKNS_2SPLIT4A: return 4;
+    default: return 0;
+    }
+}
+
+/* fnft__nse_discretization.c:108-200 */
+int orc_nse_to_akns(int d)
+{
+    switch (d) {
+    case ORC_NSE_2SPLIT2_MODAL: return ORC_AKNS_2SPLIT2_MODAL;
+    case ORC_NSE_2SPLIT1A: return ORC_AKNS_2SPLIT1A;
+    case ORC_NSE_2SPLIT1B: return ORC_AKNS_2SPLIT1B;
+    case ORC_NSE_2SPLIT2A: return ORC_AKNS_2SPLIT2A;
+    case ORC_NSE_2SPLIT2B: return ORC_AKNS_2SPLIT2B;
+    case ORC_NSE_2SPLIT2S: return ORC_AKNS_2SPLIT2S;
+    case ORC_NSE_2SPLIT3A: return ORC_AKNS_2SPLIT3A;
+    case ORC_NSE_2SPLIT3B: return ORC_AKNS_2SPLIT3B;
+    case ORC_NSE_2SPLIT3S: return ORC_AKNS_2SPLIT3S;
+    case ORC_NSE_2SPLIT4A: return ORC_AKNS_2SPLIT4A;
+    case ORC_NSE_2SPLIT4B: return ORC_AKNS_2SPLIT4B;
+    default: return -1;
+    }
+}
+
+/* expm([[0,q],[r,0]]*h) = [[c, q*s],[r*s, c]], fnft__akns_fscatter.c:46-59 */
+typedef struct { orc_cplx c, qs, rs; } step_exp;
+static step_exp zero_freq_step(double h, orc_cplx q, orc_cplx r)
+{
+    step_exp e;
+    orc_cplx Delta = h * csqrt(-q * r);
+    orc_cplx del = h * orc_csinc(Delta);
+    e.c = ccos(Delta);
+    e.qs = q * del;
+    e.rs = r * del;
+    return e;
+}
+
+size_t orc_akns_fscatter_numel(size_t D, int disc)
+{
+    size_t deg = orc_akns_degree(disc);
+    return deg == 0 ? 0 : orc_poly_fmult2x2_numel(deg, D);
+}
+
+/* fnft__akns_fscatter.c:116-917: block j of each entry belongs to sample D-1-j,
+ * coefficients highest power of z first. */
+int orc_akns_coeffs(size_t D, const orc_cplx *q, const orc_cplx *r, double eps_t, orc_cplx *p,
+                    int disc)
+{
+    const size_t deg = orc_akns_degree(disc);
+    if (deg == 0) return ORC_EC_INVALID_ARGUMENT;
+    const size_t w = deg + 1;
+    orc_cplx *p11 = p, *p12 = p + D * w, *p21 = p + 2 * D * w, *p22 = p + 3 * D * w;
+    const double h = eps_t / (double)deg;
+    for (size_t j = 0; j < D; j++, p11 += w, p12 += w, p21 += w, p22 += w) {
+        const orc_cplx qi = q[D - 1 - j], ri = r[D - 1 - j];
+        for (size_t k = 0; k < w; k++) p11[k] = p12[k] = p21[k] = p22[k] = 0.0;
+        switch (disc) {
+        case ORC_AKNS_2SPLIT2_MODAL: { /* :118-148 */
+            if (creal(qi) == creal(ri) && eps_t * cabs(qi) >= 1.0) return ORC_EC_OTHER;
+            const orc_cplx s = 1.0 / csqrt(1 - eps_t * qi * eps_t * ri);
+            p11[1] = s; p12[0] = s * eps_t * qi; p21[1] = s * eps_t * ri; p22[0] = s;
+            break;
+        }
+        case ORC_AKNS_2SPLIT1A: { /* :150-176 */
+            step_exp e = zero_freq_step(h, qi, ri);
+            p11[1] = e.c; p12[1] = e.qs; p21[0] = e.rs; p22[0] = e.c;
+            break;
+        }
+        case ORC_AKNS_2SPLIT1B: case ORC_AKNS_2SPLIT2A: { /* :178-203 */
+            step_exp e = zero_freq_step(h, qi, ri);
+            p11[1] = e.c; p12[0] = e.qs; p21[1] = e.rs; p22[0] = e.c;
+            break;
+        }
+        case ORC_AKNS_2SPLIT2B: { /* :204-228 */
+            step_exp e = zero_freq_step(0.5 * h, qi, ri);
+            p11[0] = e.qs * e.rs; p11[1] = e.c * e.c;
+            p12[0] = p12[1] = e.c * e.qs;
+            p21[0] = p21[1] = e.c * e.rs;
+            p22[0] = p11[1]; p22[1] = p11[0];
+            break;
+        }
+        case ORC_AKNS_2SPLIT2S: { /* :230-254 */
+            step_exp e = zero_freq_step(h, qi, ri);
+            p11[1] = e.c; p12[0] = p12[1] = e.qs / 2; p21[0] = p21[1] = e.rs / 2; p22[0] = e.c;
+            break;
+        }
+        case ORC_AKNS_2SPLIT3A: { /* :256-292 */
+            step_exp e1 = zero_freq_step(h, qi, ri), e2 = zero_freq_step(2 * h, qi, ri),
+                     e3 = zero_freq_step(3 * h, qi, ri);
+            p11[1] = 9 * e1.rs * e2.qs / 8; p11[3] = (9 * e1.c * e2.c - e3.c) / 8;
+            p12[1] = 9 * e1.c * e2.qs / 8;  p12[3] = (9 * e1.qs * e2.c - e3.qs) / 8;
+            p21[0] = (9 * e1.rs * e2.c - e3.rs) / 8; p21[2] = 9 * e1.c * e2.rs / 8;
+            p22[0] = p11[3]; p22[2] = 9 * e1.qs * e2.rs / 8;
+            break;
+        }
+        case ORC_AKNS_2SPLIT3B: { /* :294-330 */
+            step_exp e1 = zero_freq_step(h, qi, ri), e2 = zero_freq_step(2 * h, qi, ri),
+                     e3 = zero_freq_step(3 * h, qi, ri);
+            p11[1] = 9 * e1.qs * e2.rs / 8; p11[3] = (9 * e1.c * e2.c - e3.c) / 8;
+            p12[0] = (9 * e1.qs * e2.c - e3.qs) / 8; p12[2] = 9 * e1.c * e2.qs / 8;
+            p21[1] = 9 * e1.c * e2.rs / 8; p21[3] = (9 * e1.rs * e2.c - e3.rs) / 8;
+            p22[0] = p11[3]; p22[2] = 9 * e1.rs * e2.qs / 8;
+            break;
+        }
+        case ORC_AKNS_2SPLIT3S: { /* :331-361 */
+            step_exp e1 = zero_freq_step(h, qi, ri), e2 = zero_freq_step(2 * h, qi, ri);
+            p11[0] = 2 * e1.qs * e1.rs / 3; p11[2] = (2 * e1.c * e1.c + e2.c) / 3;
+            p12[0] = p12[2] = (4 * e1.c * e1.qs - e2.qs) / 6; p12[1] = 2 * e2.qs / 3;
+            p21[0] = p21[2] = (4 * e1.c * e1.rs - e2.rs) / 6; p21[1] = 2 * e2.rs / 3;
+            p22[0] = p11[2]; p22[2] = p11[0];
+            break;
+        }
+        case ORC_AKNS_2SPLIT4A: { /* :362-401 */
+            step_exp e2 = zero_freq_step(2 * h, qi, ri), e4 = zero_freq_step(4 * h, qi, ri);
+            p11[2] = 4 * e2.qs * e2.rs / 3; p11[4] = (4 * e2.c * e2.c - e4.c) / 3;
+            p12[1] = p12[3] = 4 * e2.c * e2.qs / 3; p12[2] = -e4.qs / 3;
+            p21[1] = p21[3] = 4 * e2.c * e2.rs / 3; p21[2] = -e4.rs / 3;
+            p22[0] = p11[4]; p22[2] = p11[2];
+            break;
+        }
+        case ORC_AKNS_2SPLIT4B: { /* :402-433 */
+            step_exp eh = zero_freq_step(0.5 * h, qi, ri), e1 = zero_freq_step(h, qi, ri);
+            p11[0] = (4 * e1.c * eh.qs * eh.rs - e1.qs * e1.rs) / 3;
+            p11[1] = 4 * (e1.qs * eh.c * eh.rs + e1.rs * eh.c * eh.qs) / 3;
+            p11[2] = (4 * e1.c * eh.c * eh.c - e1.c * e1.c) / 3;
+            p12[0] = p12[2] = (4 * e1.c * eh.c * eh.qs - e1.c * e1.qs) / 3;
+            p12[1] = 4 * (e1.qs * eh.c * eh.c + e1.rs * eh.qs * eh.qs) / 3;
+            p21[0] = p21[2] = (4 * e1.c * eh.c * eh.rs - e1.c * e1.rs) / 3;
+            p21[1] = 4 * (e1.rs * eh.c * eh.c + e1.qs * eh.rs * eh.rs) / 3;
+            p22[0] = p11[2]; p22[1] = p11[1]; p22[2] = p11[0];
+            break;
+        }
+        default: return ORC_EC_INVALID_ARGUMENT;
+        }
+    }
+    return ORC_SUCCESS;
+}
+
+/* fnft__akns_fscatter.c:64-925 */
+int orc_akns_fscatter(size_t D, const orc_cplx *q, const orc_cplx *r, double eps_t,
+                      orc_cplx *result, size_t *deg_ptr, int32_t *W_ptr, int disc)
+{
+    if (D == 0 || !q || !r || !(eps_t > 0.0) || !result || !deg_ptr)
+        return ORC_EC_INVALID_ARGUMENT;
+    const size_t numel = orc_akns_fscatter_numel(D, disc);
+    if (numel == 0) return ORC_EC_INVALID_ARGUMENT;
+    orc_cplx *p = malloc(numel * sizeof(orc_cplx));
+    if (!p) return ORC_EC_NOMEM;
+    *deg_ptr = orc_akns_degree(disc);
+    int rc = orc_akns_coeffs(D, q, r, eps_t, p, disc);
+    if (rc == ORC_SUCCESS) rc = orc_poly_fmult2x2(deg_ptr, D, p, result, W_ptr);
+    free(p);
+    return rc;
+}
+
+/* fnft__nse_fscatter.c:34-42 */
+size_t orc_nse_fscatter_numel(size_t D, int nse_disc)
+{
+    int a = orc_nse_to_akns(nse_disc);
+    return a < 0 ? 0 : orc_akns_fscatter_numel(D, a);
+}
+
+/* fnft__nse_fscatter.c:44-91 */
+int orc_nse_fscatter(size_t D, const orc_cplx *q, double eps_t, int kappa, orc_cplx *result,
+                     size_t *deg_ptr, int32_t *W_ptr, int nse_disc)
+{
+    if (D == 0 || !q || !(eps_t > 0.0) || abs(kappa) != 1 || !result || !deg_ptr)
+        return ORC_EC_INVALID_ARGUMENT;
+    const int a = orc_nse_to_akns(nse_disc);
+    if (a < 0) return ORC_EC_INVALID_ARGUMENT;
+    orc_cplx *r = malloc(D * sizeof(orc_cplx));
+    if (!r) return ORC_EC_NOMEM;
+    for (size_t i = 0; i < D; i++) r[i] = (kappa == 1) ? -conj(q[i]) : conj(q[i]);
+    int rc = orc_akns_fscatter(D, q, r, eps_t, result, deg_ptr, W_ptr, a);
+    free(r);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* continuous spectrum                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* fnft__nse_discretization.c:240-379; boundary coefficient 0.5 (fnft__akns_discretization.c:72-109) */
+static void phase_factors(int nse_disc, double eps_t, size_t D, const double *T, double *rho,
+                          double *a, double *b)
+{
+    const double bc = 0.5;
+    const int shifted = (nse_disc == ORC_NSE_2SPLIT2A || nse_disc == ORC_NSE_2SPLIT2_MODAL);
+    const double deg = (double)orc_akns_degree(orc_nse_to_akns(nse_disc));
+    *rho = -2.0 * (T[1] + eps_t * bc) + (shifted ? eps_t / deg : 0.0);
+    *a = -eps_t * (double)D + (T[1] + eps_t * bc) - (T[0] - eps_t * bc);
+    *b = -eps_t * (double)D - (T[1] + eps_t * bc) - (T[0] - eps_t * bc) + (shifted ? eps_t / deg : 0.0);
+}
+
+/* fnft_nsev.c:744-891, fast (polynomial) branch */
+int orc_nsev_contspec(size_t deg, int32_t W, const orc_cplx *tm, const double *T, size_t D,
+                      const double *XI, size_t M, orc_cplx *result, int nse_disc, int cstype)
+{
+    const int a_disc = orc_nse_to_akns(nse_disc);
+    if (a_disc < 0) return ORC_EC_INVALID_ARGUMENT;
+    const double deg1 = (double)orc_akns_degree(a_disc);
+    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
+    const double eps_xi = (XI[1] - XI[0]) / (double)(M - 1);
+    orc_cplx *H = malloc(2 * M * sizeof(orc_cplx));
+    if (!H) return ORC_EC_NOMEM;
+    orc_cplx *H11 = H, *H21 = H + M;
+    /* lambda -> z (fnft__akns_discretization.c:204-219), fnft_nsev.c:822-827 */
+    const orc_cplx V = cexp(2 * I * (orc_cplx)eps_xi * eps_t / deg1);
+    const orc_cplx A = cexp(2 * I * (orc_cplx)(-XI[0]) * eps_t / deg1);
+    int rc = orc_poly_chirpz(deg, tm, A, V, M, H11);
+    if (rc == ORC_SUCCESS) rc = orc_poly_chirpz(deg, tm + 2 * (deg + 1), A, V, M, H21);
+    if (rc != ORC_SUCCESS) { free(H); return rc; }
+    double pf_rho, pf_a, pf_b;
+    phase_factors(nse_disc, eps_t, D, T, &pf_rho, &pf_a, &pf_b);
+    size_t offset = 0;
+    if (cstype != ORC_CS_RHO && cstype != ORC_CS_AB && cstype != ORC_CS_BOTH) {
+        free(H);
+        return ORC_EC_INVALID_ARGUMENT;
+    }
+    if (cstype == ORC_CS_BOTH) offset = M;
+    if (cstype == ORC_CS_RHO || cstype == ORC_CS_BOTH) { /* :844-855 */
+        for (size_t i = 0; i < M; i++) {
+            const orc_cplx xi = XI[0] + eps_xi * (double)i;
+            if (H11[i] == 0.0) { free(H); return ORC_EC_DIV_BY_ZERO; }
+            result[i] = H21[i] * cexp(I * xi * pf_rho) / H11[i];
+        }
+    }
+    if (cstype == ORC_CS_AB || cstype == ORC_CS_BOTH) { /* :861-876 */
+        const double scale = pow(2.0, W);
+        for (size_t i = 0; i < M; i++) {
+            const orc_cplx xi = XI[0] + eps_xi * (double)i;
+            result[offset + i] = H11[i] * scale * cexp(I * xi * pf_a);
+            result[offset + M + i] = H21[i] * scale * cexp(I * xi * pf_b);
+        }
+    }
+    free(H);
+    return ORC_SUCCESS;
+}
+
+/* fnft_nsev.c:133-453 + 458-565, contspec-only subset (see header) */
+int orc_fnft_nsev(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
+                  const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag)
+{
+    if (D < 2 || !q || !T || !(T[0] < T[1])) return ORC_EC_INVALID_ARGUMENT;
+    if (contspec && (!XI || !(XI[0] < XI[1]))) return ORC_EC_INVALID_ARGUMENT;
+    if (abs(kappa) != 1) return ORC_EC_INVALID_ARGUMENT;
+    const size_t numel = orc_nse_fscatter_numel(D, nse_disc);
+    if (numel == 0) return ORC_EC_INVALID_ARGUMENT;
+    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
+    orc_cplx *tm = malloc(numel * sizeof(orc_cplx));
+    if (!tm) return ORC_EC_NOMEM;
+    size_t deg = 0;
+    int32_t W = 0;
+    double t0 = now_s();
+    int rc = orc_nse_fscatter(D, q, eps_t, kappa, tm, &deg, normalization_flag ? &W : NULL, nse_disc);
+    double t1 = now_s();
+    if (rc == ORC_SUCCESS && contspec && M > 0)
+        rc = orc_nsev_contspec(deg, W, tm, T, D, XI, M, contspec, nse_disc, cstype);
+    double t2 = now_s();
+    g_timings[0] = t1 - t0;
+    g_timings[1] = t2 - t1;
+    free(tm);
+    /* subroutine failures surface as -abs(ec), fnft__errwarn.h:50-57,101 */
+    return rc == ORC_SUCCESS ? rc : -abs(rc);
+}

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Extract the reference's own known-answer vectors for the fnft_nsev hot path into a fixture.
+
+Run once in the build container (needs /root/reference); the output
+tests/golden/reference_fixtures.json is committed and is all the tests read.  Only NUMBERS are
+extracted (inputs, expected outputs, tolerances) -- no source text is kept.
+
+Sources (relative to /root/reference):
+  test/fnft__poly/fnft__poly_fmult2x2_test_n_is_power_of_2.c:61-81      (tree, n=4, deg 1)
+  test/fnft__poly/fnft__poly_fmult2x2_test_n_is_no_power_of_2.c:68-92   (tree, n=5, deg 1)
+  test/fnft__poly/fnft__poly_chirpz_test.c:28-40                         (chirp-z, deg 3)
+  test/fnft__fft_wrapper/fnft__fft_wrapper_test.c                        (length-4 FFT)
+  test/fnft__akns_fscatter/*.c                                           (per-scheme transfer matrices)
+  src/private/fnft__nsev_testcases.c:142-287,463-567                     (analytic spectra)
+  test/fnft_nsev/*.c                                                     (per-scheme error bounds)
+"""
+import json
+import os
+import re
+import sys
+
+REF = os.environ.get("FNFT_REFERENCE", "/root/reference")
+
+
+def read(rel):
+    with open(os.path.join(REF, rel)) as f:
+        return f.read()
+
+
+def strip_comments(s):
+    s = re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+    s = re.sub(r"//[^\n]*", "", s)
+    return s
+
+
+def ceval(expr):
+    """Evaluate a C complex literal expression such as '1.5 - I*2' or '3 + -2e-1*I'."""
+    e = expr.replace("\\", " ").replace("\n", " ").strip()
+    e = re.sub(r"\bI\b", "1j", e)
+    if not re.fullmatch(r"[0-9eE+\-*/.()j\s]+", e):
+        raise ValueError("unexpected token in %r" % expr)
+    return complex(eval(e, {"__builtins__": {}}, {}))
+
+
+def c2l(z):
+    return [z.real, z.imag]
+
+
+def array_init(src, name):
+    m = re.search(re.escape(name) + r"\s*\[[^\]]*\]\s*=\s*\{(.*?)\}\s*;", src, flags=re.S)
+    if not m:
+        raise KeyError(name)
+    body = m.group(1)
+    return [ceval(x) for x in body.split(",") if x.strip()]
+
+
+def main():
+    out = {"_generated_by": "tests/golden/extract_reference_fixtures.py",
+           "_reference": "IgorChekhovskoy/FNFT @ 2025-01-27 (FNFT 0.4.1)"}
+
+    # ---- product tree -------------------------------------------------------------------
+    for key, rel, n in (
+        ("fmult2x2_pow2", "test/fnft__poly/fnft__poly_fmult2x2_test_n_is_power_of_2.c", 4),
+        ("fmult2x2_nopow2", "test/fnft__poly/fnft__poly_fmult2x2_test_n_is_no_power_of_2.c", 5),
+    ):
+        src = strip_comments(read(rel))
+        exact = array_init(src, "result_exact")
+        # input rule stated in the test: p_e[i] = sqrt(i+1)*(cos(i+0.1e) + 1j*sin(-2i+0.1e))
+        out[key] = {
+            "deg": 1, "n": n,
+            "input_rule": "p[e*n*(deg+1)+i] = sqrt(i+1)*(cos(i+0.1*e) + 1j*sin(-2*i+0.1*e)), e=0..3",
+            "result_exact": [c2l(z) for z in exact],
+            "tol_rel_l1": 100 * 2.220446049250313e-16,
+        }
+
+    # ---- chirp z ------------------------------------------------------------------------
+    src = strip_comments(read("test/fnft__poly/fnft__poly_chirpz_test.c"))
+    out["chirpz"] = {
+        "deg": 3,
+        "p": [c2l(z) for z in array_init(src, "p")],
+        "A": [0.95, 0.0],
+        "W_arg": 0.3,  # W = exp(0.3i)
+        "result_M3": [c2l(z) for z in array_init(src, "result_exactM3")],
+        "result_M6": [c2l(z) for z in array_init(src, "result_exactM6")],
+        "tol_rel_l1": 100 * 2.220446049250313e-16,
+    }
+
+    # ---- fft wrapper ---------------------------------------------------------------------
+    src = strip_comments(read("test/fnft__fft_wrapper/fnft__fft_wrapper_test.c"))
+    fft = {}
+    for nm in re.findall(r"COMPLEX\s+(\w+)\s*\[[^\]]*\]\s*=\s*\{", src):
+        fft[nm] = [c2l(z) for z in array_init(src, nm)]
+    out["fft_wrapper"] = fft
+
+    # ---- akns_fscatter, one entry per splitting scheme ------------------------------------
+    schemes = {}
+    d = os.path.join(REF, "test/fnft__akns_fscatter")
+    for fn in sorted(os.listdir(d)):
+        src = strip_comments(read("test/fnft__akns_fscatter/" + fn))
+        name = re.search(r"akns_discretization_(\w+)\s*;", src).group(1)
+        eps = float(re.search(r"eps_t\s*=\s*([0-9.eE+-]+)\s*;", src).group(1))
+        D = int(re.search(r"\bD\s*=\s*(\d+)", src).group(1))
+        schemes[name] = {
+            "D": D, "eps_t": eps,
+            "result_exact": [c2l(z) for z in array_init(src, "result_exact")],
+        }
+    out["akns_fscatter"] = {
+        "input_rule": {
+            "q": "(0.41*cos(n) + 0.59j*sin(0.28*n))*50, n=1..D",
+            "r": "(0.33*sin(n) + 0.85j*cos(0.43*n))*25, n=1..D",
+            "z_args": [0.0, "pi/4", "9*pi/14", "4*pi/3", "-pi/5"],
+            "layout": "result_exact[e*5+j] = S_e(z_j), e in (11,12,21,22)",
+        },
+        "tol_rel_l1": 100 * 2.220446049250313e-16,
+        "schemes": schemes,
+    }
+
+    # ---- analytic spectra ------------------------------------------------------------------
+    src = strip_comments(read("src/private/fnft__nsev_testcases.c"))
+
+    def case_block(tag):
+        # body of the LAST "case nsev_testcases_<tag>:" (the one that fills in the values)
+        idx = [m.start() for m in re.finditer(r"case\s+nsev_testcases_" + tag + r"\s*:", src)][-1]
+        end = src.find("break;", idx)
+        return src[idx:end]
+
+    def assigns(block, ptr):
+        vals = {}
+        for m in re.finditer(r"\(\*" + ptr + r"\)\[(\d+)\]\s*=\s*([^;]+);", block):
+            vals[int(m.group(1))] = ceval(m.group(2))
+        return [c2l(vals[i]) for i in range(len(vals))]
+
+    blk = case_block("SECH_FOCUSING")
+    out["nsev_sech_focusing"] = {
+        "signal": "q[i] = 1j*3.2*sech(T0 + i*(T1-T0)/(D-1))",
+        "T": [-25.0, 25.0], "XI": [-7.0 / 5.0, 8.0 / 5.0], "M": 16, "kappa": 1,
+        "contspec": assigns(blk, "contspec_ptr"),
+        "ab": assigns(blk, "ab_ptr"),
+    }
+    blk = case_block("SECH_DEFOCUSING")
+    out["nsev_sech_defocusing"] = {
+        "signal": "q[i] = -conj(Q/GAM*sech(t/GAM)**(1-2j*F)), Q=1, GAM=1/25, F=1.5",
+        "T": [-2.0, 1.5], "XI": [-100.0, 80.0], "M": 16, "kappa": -1,
+        "contspec": assigns(blk, "contspec_ptr"),
+    }
+    out["nsev_truncated_soliton"] = {
+        "signal": "q[i] = -2*be*sech(2*be*t), q[0] *= 0.5, be=0.55",
+        "T": [0.0, 15.0], "XI": [0.5, 3.0], "M": 16, "kappa": 1,
+        "contspec_rule": "-1j*be/xi*(xi+1j*be)/(xi-1j*be)",
+    }
+
+    # ---- per-scheme error bounds of the integration tests ----------------------------------
+    bounds = []
+    d = os.path.join(REF, "test/fnft_nsev")
+    for fn in sorted(os.listdir(d)):
+        src = strip_comments(read("test/fnft_nsev/" + fn))
+        mtc = re.search(r"nsev_testcases_(SECH_FOCUSING2|SECH_FOCUSING|SECH_DEFOCUSING|TRUNCATED_SOLITON)\b", src)
+        mdisc = re.search(r"opts\.discretization\s*=\s*nse_discretization_(\w+)\s*;", src)
+        mD = re.search(r"UINT\s+D\s*=\s*(\d+)\s*;", src)
+        mb = re.search(r"error_bounds\s*\[\s*6\s*\]\s*=\s*\{(.*?)\}\s*;", src, flags=re.S)
+        if not (mtc and mD and mb):
+            continue
+        vals = []
+        for x in mb.group(1).split(","):
+            x = x.strip()
+            if not x:
+                continue
+            x = x.replace("INFINITY", "float('inf')").replace("FNFT_INF", "float('inf')")
+            vals.append(float(eval(x, {"__builtins__": {}, "float": float}, {})))
+        # second stage of each test: D doubles and the bounds are rescaled by the statements
+        # between "D *= 2;" and the next harness call
+        vals2 = None
+        m2 = re.search(r"D\s*\*=\s*2\s*;(.*?)nsev_testcases_test_fnft", src, flags=re.S)
+        if m2:
+            vals2 = list(vals)
+            for op in re.finditer(r"error_bounds\s*\[\s*(\w+)\s*\]\s*([*/])=\s*([0-9.eE+-]+)\s*;", m2.group(1)):
+                idx, sign, fac = op.group(1), op.group(2), float(op.group(3))
+                targets = range(len(vals2)) if not idx.isdigit() else [int(idx)]
+                for t in targets:
+                    vals2[t] = vals2[t] * fac if sign == "*" else vals2[t] / fac
+        bounds.append({
+            "file": fn, "testcase": mtc.group(1),
+            "discretization": mdisc.group(1) if mdisc else "2SPLIT4B",
+            "D": int(mD.group(1)), "error_bounds": vals[:3],
+            "error_bounds_2D": vals2[:3] if vals2 else None,
+        })
+    out["nsev_error_bounds"] = bounds
+
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_fixtures.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", dst, "with", len(schemes), "akns schemes,", len(bounds), "bound sets")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

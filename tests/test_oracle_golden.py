@@ -1,0 +1,171 @@
+"""Pin the CPU oracle against the reference's own known-answer vectors (no GPU needed).
+
+Each test mirrors one of the reference's tests and uses the same tolerance:
+  test/fnft__poly/fnft__poly_fmult2x2_test_n_is_power_of_2.c / ..._no_power_of_2.c   (100 eps)
+  test/fnft__poly/fnft__poly_chirpz_test.c                                            (100 eps)
+  test/fnft__fft_wrapper/fnft__fft_wrapper_test.c
+  test/fnft__akns_fscatter/*.c                                                        (100 eps)
+  test/fnft_nsev/*.c via src/private/fnft__nsev_testcases.c:711-822 (per-scheme error bounds)
+"""
+import numpy as np
+import pytest
+
+import signals as S
+from oracle.oracle import AKNS_DISC, NSE_DISC
+
+EPS = np.finfo(np.float64).eps
+
+
+def test_next_fast_size(oracle):
+    # kiss_fft.c:396-408; schedule quoted in SURVEY App. B
+    assert [oracle.next_fast_size(n) for n in (3, 5, 9, 17, 33, 7, 11, 1)] == [3, 5, 9, 18, 36, 8, 12, 1]
+    assert oracle.next_fast_size(2 ** 20 + 1) == 1049760
+    assert oracle.next_fast_size(2 ** 21) == 2097152
+
+
+def test_fft_known_answer(oracle, fixtures):
+    fx = fixtures["fft_wrapper"]
+    x, y = S.l2c(fx["in_exact"]), S.l2c(fx["out_exact"])
+    assert S.rel_err(oracle.fft(x, -1), y) < 100 * EPS
+    assert S.rel_err(oracle.fft(y, +1) / x.size, x) < 100 * EPS
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 25, 27, 30, 36, 45,
+                               60, 64, 81, 100, 125, 128, 360, 1000, 1024, 1080])
+def test_fft_matches_numpy(oracle, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    assert np.allclose(oracle.fft(x, -1), np.fft.fft(x), rtol=0, atol=1e-12 * np.sqrt(n) * 4)
+    assert np.allclose(oracle.fft(x, +1), np.fft.ifft(x) * n, rtol=0, atol=1e-12 * np.sqrt(n) * 4)
+
+
+@pytest.mark.parametrize("key", ["fmult2x2_pow2", "fmult2x2_nopow2"])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_poly_fmult2x2_golden(oracle, fixtures, key, normalize):
+    fx = fixtures[key]
+    deg, n = fx["deg"], fx["n"]
+    exact = S.l2c(fx["result_exact"])
+    p = S.fmult_test_input(deg, n)
+    d, res, W = oracle.poly_fmult2x2(deg, n, p, normalize=normalize)
+    assert d == exact.size // 4 - 1
+    if normalize:
+        assert W != 0
+        res = res * 2.0 ** W
+    assert S.rel_err(res.ravel(), exact) <= fx["tol_rel_l1"]
+
+
+@pytest.mark.parametrize("deg,n", [(1, 2), (1, 7), (2, 8), (2, 13), (3, 6), (4, 5), (1, 64), (2, 100)])
+def test_poly_fmult2x2_vs_direct_convolution(oracle, deg, n):
+    rng = np.random.default_rng(100 * deg + n)
+    p = rng.standard_normal((4, n * (deg + 1))) + 1j * rng.standard_normal((4, n * (deg + 1)))
+    d, res, W = oracle.poly_fmult2x2(deg, n, p, normalize=True)
+    ref = S.tree_direct(p, deg, n)
+    assert d == deg * n
+    assert S.rel_err((res * 2.0 ** W).ravel(), ref.ravel()) < 1e-13
+
+
+def test_poly_chirpz_golden(oracle, fixtures):
+    fx = fixtures["chirpz"]
+    p = S.l2c(fx["p"])
+    A = complex(*fx["A"])
+    W = np.exp(1j * fx["W_arg"])
+    for M, key in ((3, "result_M3"), (6, "result_M6")):
+        out = oracle.poly_chirpz(p, A, W, M)
+        assert S.rel_err(out, S.l2c(fx[key])) <= fx["tol_rel_l1"]
+
+
+@pytest.mark.parametrize("scheme", sorted(AKNS_DISC))
+@pytest.mark.parametrize("normalize", [False, True])
+def test_akns_fscatter_golden(oracle, fixtures, scheme, normalize):
+    fx = fixtures["akns_fscatter"]["schemes"][scheme]
+    q, r, z = S.akns_test_signal(fx["D"])
+    rc, deg, tm, W = oracle.akns_fscatter(q, r, fx["eps_t"], scheme, normalize=normalize)
+    assert rc == 0
+    if normalize:
+        assert W != 0
+        tm = tm * 2.0 ** W
+    vals = np.concatenate([oracle.poly_eval(tm[e], z) for e in range(4)])
+    assert S.rel_err(vals, S.l2c(fx["result_exact"])) <= fixtures["akns_fscatter"]["tol_rel_l1"]
+
+
+def _nsev_errors(oracle, fixtures, testcase, disc, D):
+    if testcase == "SECH_FOCUSING":
+        fx = fixtures["nsev_sech_focusing"]
+        q = S.sech_focusing(D)
+        exact_rho = S.l2c(fx["contspec"])
+        exact_ab = S.l2c(fx["ab"])
+    elif testcase == "SECH_DEFOCUSING":
+        fx = fixtures["nsev_sech_defocusing"]
+        q = S.sech_defocusing(D)
+        exact_rho = S.l2c(fx["contspec"])
+        exact_ab = None
+    else:
+        fx = fixtures["nsev_truncated_soliton"]
+        q = S.truncated_soliton(D)
+        exact_rho = S.truncated_soliton_contspec(fx["XI"], fx["M"])
+        exact_ab = None
+    M = fx["M"]
+    rc, cs = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=fx["kappa"], disc=disc, cstype="BOTH")
+    assert rc == 0
+    errs = [S.rel_err(cs[:M], exact_rho)]
+    if exact_ab is not None:
+        errs += [S.rel_err(cs[M:2 * M], exact_ab[:M]), S.rel_err(cs[2 * M:], exact_ab[M:])]
+    return errs
+
+
+def _bound_cases(fixtures_path="tests/golden/reference_fixtures.json"):
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, fixtures_path)) as f:
+        fx = json.load(f)
+    cases = []
+    for b in fx["nsev_error_bounds"]:
+        if b["discretization"] in AKNS_DISC and b["testcase"] != "SECH_FOCUSING2" \
+                and np.isfinite(b["error_bounds"][0]):
+            cases.append(pytest.param(b, id=b["file"].replace("fnft_nsev_test_", "").replace(".c", "")))
+    return cases
+
+
+@pytest.mark.parametrize("b", _bound_cases())
+def test_fnft_nsev_analytic_bounds(oracle, fixtures, b):
+    """fnft__nsev_testcases.c:711-822 run at D, D+1, D-1 and at 2D with the test's own rescaled
+    bounds (order-of-convergence check, test/fnft_nsev/*.c)."""
+    D = b["D"]
+    stages = [(D, b["error_bounds"]), (D + 1, b["error_bounds"]), (D - 1, b["error_bounds"])]
+    if b.get("error_bounds_2D"):
+        stages.append((2 * D, b["error_bounds_2D"]))
+    for DD, bounds in stages:
+        errs = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], DD)
+        for e, bound in zip(errs, bounds):
+            if np.isfinite(bound):
+                assert e <= bound, (DD, errs, b)
+
+
+def test_modal_defocusing_step_check(oracle):
+    """fnft__akns_fscatter.c:122-126: MODAL raises E_OTHER (5) when Re q == Re r and eps_t*|q| >= 1;
+    fnft_nsev returns it wrapped as -5 (fnft__errwarn.h:50-57,101)."""
+    q = np.full(16, 40.0 + 0j)
+    rc, _ = oracle.fnft_nsev(q, [0.0, 1.0], 8, [-1.0, 1.0], kappa=-1, disc="2SPLIT2_MODAL")
+    assert rc == -5
+
+
+def test_validation_codes(oracle):
+    q = np.ones(8, np.complex128)
+    assert oracle.fnft_nsev(q[:1], [0, 1], 4, [-1, 1])[0] == 2          # D < 2
+    assert oracle.fnft_nsev(q, [1, 0], 4, [-1, 1])[0] == 2              # T
+    assert oracle.fnft_nsev(q, [0, 1], 4, [1, -1])[0] == 2              # XI
+    assert oracle.fnft_nsev(q, [0, 1], 4, [-1, 1], kappa=2)[0] == 2     # kappa
+    assert oracle.fnft_nsev(q, [0, 1], 4, [-1, 1], disc=NSE_DISC["2SPLIT8B"])[0] == 2  # not covered
+
+
+def test_cstype_layouts(oracle):
+    q = S.sech_focusing(256)
+    T, XI, M = [-25.0, 25.0], [-1.4, 1.6], 16
+    _, both = oracle.fnft_nsev(q, T, M, XI, disc="2SPLIT4B", cstype="BOTH")
+    _, rho = oracle.fnft_nsev(q, T, M, XI, disc="2SPLIT4B", cstype="RHO")
+    _, ab = oracle.fnft_nsev(q, T, M, XI, disc="2SPLIT4B", cstype="AB")
+    assert np.array_equal(both[:M], rho) and np.array_equal(both[M:], ab)
+    # rho = b/a up to the phase factors, independent of normalisation
+    _, nonorm = oracle.fnft_nsev(q, T, M, XI, disc="2SPLIT4B", cstype="BOTH", normalize=False)
+    assert S.rel_err(nonorm, both) < 1e-12
