@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fnft_nsev continuous-spectrum hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full pass of the hot path (per-sample AKNS coefficients -> 2x2 polynomial product
+tree -> chirp z-transform -> a, b, rho) over one synthetic signal of BASELINE.json's configs[1]:
+D = M = 2^20 complex128 samples, q = 3.2i*sech(t), T = [-25, 25], XI = [-7/5, 8/5],
+2SPLIT2_MODAL, contspec_type BOTH, normalisation on.  Inputs and outputs are resident in HBM.
+
+With N ranks every rank transforms its own signal (weak scaling, no data-path collective) and
+the result shards are gathered on rank 0 with one RCCL gather per step, overlapped with the next
+step's compute on RCCL's stream.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def bytes_tree(D, deg0):
+    """Algorithmic bytes of the product tree, SURVEY.md section 8d:
+    sum over levels of 64*[n(d+1) + (n/2)(2d+1)] = 128*D*deg0*log2(D) + 192*(D-1)."""
+    return 128 * D * deg0 * int(round(math.log2(D))) + 192 * (D - 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2D", type=int, default=20)
+    ap.add_argument("--disc", default="2SPLIT2_MODAL")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fnft_amd import capi
+    import signals as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    D = M = 1 << args.log2D
+    deg0 = {"2SPLIT2_MODAL": 1, "2SPLIT4B": 2}.get(args.disc, 1)
+    T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
+    # each rank gets its own (slightly different) signal so that no rank can reuse another's work
+    q_host = S.sech_focusing(D, amp=3.2 - 0.01 * rank)
+
+    plan = capi.Plan(D, M, batch=1, discretization=args.disc, device=local_rank)
+    plan.set_timing(True)
+    dq = torch.from_numpy(q_host).cuda()
+    outs = [torch.zeros(3 * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
+    gather_bufs = None
+    if world > 1 and rank == 0 and not args.no_gather:
+        gather_bufs = [[torch.zeros(3 * M, 2, dtype=torch.float64, device="cuda") for _ in range(world)]
+                       for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one_step(i, pending):
+        buf = outs[i % 2]
+        rc = plan.contspec_device(dq.data_ptr(), buf.data_ptr(), T, XI, kappa=1, contspec_type="BOTH",
+                                  normalization_flag=1, stream=stream)
+        if rc != 0:
+            raise RuntimeError("fnft_amd_nsev_contspec_device rc=%d: %s" % (rc, capi.last_error()))
+        if world > 1 and not args.no_gather:
+            # the buffer written two steps ago must have been gathered before it is reused
+            if len(pending) >= 2:
+                pending.pop(0).wait()
+            w = dist.gather(torch.view_as_real(buf), gather_bufs[i % 2] if rank == 0 else None, dst=0,
+                            async_op=True)
+            pending.append(w)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pending = []
+    for i in range(args.warmup):
+        one_step(i, pending)
+    for w in pending:
+        w.wait()
+    pending = []
+    rc = plan.finish(stream)
+    if rc != 0:
+        raise RuntimeError("device status rc=%d: %s" % (rc, capi.last_error()))
+
+    # ---- timed region: exactly K steps between barrier + synchronize pairs -----------------
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    tree_ms_sum = 0.0
+    for i in range(args.steps):
+        one_step(i, pending)
+    for w in pending:
+        w.wait()
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    wall_ms = (t1 - t0) * 1e3
+    ev_ms = ev0.elapsed_time(ev1)
+    # HIP-event timers of the last step, recorded on the launch stream inside the plan
+    tree_ms = plan.last_ms(0)
+    chirp_ms = plan.last_ms(1)
+    rc = plan.finish(stream)
+    if rc != 0:
+        raise RuntimeError("device status rc=%d: %s" % (rc, capi.last_error()))
+
+    t_all = torch.tensor([wall_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    wall_ms_max = float(t_all.item())
+    ms_per_step = wall_ms_max / args.steps
+    value = world * D / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
+
+    # ---- tree-only timing with HIP events over many passes (roofline) -----------------------
+    roof = None
+    cpu = None
+    if rank == 0:
+        reps = max(5, args.steps)
+        tms = []
+        for i in range(reps):
+            plan.contspec_device(dq.data_ptr(), outs[0].data_ptr(), T, XI, 1, "BOTH", 1, stream)
+            torch.cuda.synchronize()
+            tms.append(plan.last_ms(0))
+        t_tree = float(np.median(tms))
+        bt = bytes_tree(D, deg0)
+        achieved = bt / (t_tree * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "poly_fmult2x2 tree (coefficients + all level launches of one transform)",
+                "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
+                "chirpz_epilogue_ms": round(float(chirp_ms), 4)}
+        if not args.no_cpu_baseline:
+            from oracle import load_oracle
+            orc = load_oracle()
+            Dc = min(D, 1 << 20)
+            qc = S.sech_focusing(Dc)
+            tc0 = time.perf_counter()
+            rcc, ref = orc.fnft_nsev(qc, T, Dc, XI, kappa=1, disc=args.disc, cstype="BOTH")
+            tc = time.perf_counter() - tc0
+            res = outs[(args.steps - 1) % 2].cpu().numpy() if Dc == D else None
+            err = None
+            if res is not None and rcc == 0:
+                err = {k: float(S.rel_err(res[j * M:(j + 1) * M], ref[j * M:(j + 1) * M]))
+                       for j, k in enumerate(("rho", "a", "b"))}
+            cpu = {"value": round(Dc / tc / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                   "sample": "1 signal, D=M=2^%d, %s, oracle/fnft_oracle.c single thread, %.1f s"
+                             % (int(math.log2(Dc)), args.disc, tc),
+                   "host_cpus": os.cpu_count(), "gpu_vs_cpu_rel_l1": err}
+
+    if rank == 0:
+        line = {
+            "metric": "Msamples/s fnft_nsev contspec (D=2^%d fp64)" % args.log2D,
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "fnft_nsev D=M=2^%d contspec (a,b + reflection), %s, 1 signal per GPU"
+                                   % (args.log2D, args.disc),
+                       "per_step_gather": bool(world > 1 and not args.no_gather),
+                       "event_ms_per_step": round(ev_ms / args.steps, 4)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

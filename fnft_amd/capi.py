@@ -1,0 +1,296 @@
+"""ctypes bindings of libfnft_amd.so -- the same C ABI a C / MATLAB-mex / FNFTpy caller of the
+reference's libfnft.so uses (include/fnft_amd.h).  Names, argument meaning and return codes
+follow the reference (include/fnft_nsev.h:371-376, include/private/fnft__poly_fmult.h:223-224,
+include/private/fnft__poly_chirpz.h:61, include/private/fnft__akns_fscatter.h:89-90,
+include/private/fnft__nse_fscatter.h:81-84).
+
+There is no CPU fallback: if the HIP library has not been built, load() raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfnft_amd.so")
+
+# return codes, include/fnft_errwarn.h:44-94
+FNFT_SUCCESS = 0
+FNFT_EC_NOMEM = 1
+FNFT_EC_INVALID_ARGUMENT = 2
+FNFT_EC_DIV_BY_ZERO = 3
+FNFT_EC_OTHER = 5
+FNFT_EC_NOT_YET_IMPLEMENTED = 6
+
+# fnft_nse_discretization_t, include/fnft_nse_discretization_t.h:104-133
+NSE_DISC = {
+    "2SPLIT2_MODAL": 0, "BO": 1, "2SPLIT1A": 2, "2SPLIT1B": 3, "2SPLIT2A": 4, "2SPLIT2B": 5,
+    "2SPLIT2S": 6, "2SPLIT3A": 7, "2SPLIT3B": 8, "2SPLIT3S": 9, "2SPLIT4A": 10, "2SPLIT4B": 11,
+    "2SPLIT5A": 12, "2SPLIT5B": 13, "2SPLIT6A": 14, "2SPLIT6B": 15, "2SPLIT7A": 16,
+    "2SPLIT7B": 17, "2SPLIT8A": 18, "2SPLIT8B": 19, "4SPLIT4A": 20, "4SPLIT4B": 21,
+    "CF4_2": 22, "CF4_3": 23, "CF5_3": 24, "CF6_4": 25, "ES4": 26, "TES4": 27,
+}
+# fnft__akns_discretization_t, include/private/fnft__akns_discretization_t.h:104-134
+AKNS_DISC = {
+    "2SPLIT2_MODAL": 0, "2SPLIT1A": 1, "2SPLIT1B": 2, "2SPLIT2A": 3, "2SPLIT2B": 4, "2SPLIT2S": 5,
+    "2SPLIT3A": 6, "2SPLIT3B": 7, "2SPLIT3S": 8, "2SPLIT4A": 9, "2SPLIT4B": 10, "2SPLIT5A": 11,
+    "2SPLIT5B": 12, "2SPLIT6A": 13, "2SPLIT6B": 14, "2SPLIT7A": 15, "2SPLIT7B": 16,
+    "2SPLIT8A": 17, "2SPLIT8B": 18, "BO": 19, "4SPLIT4A": 20, "4SPLIT4B": 21,
+}
+CSTYPE = {"RHO": 0, "REFLECTION_COEFFICIENT": 0, "AB": 1, "BOTH": 2}
+CS_FACTOR = {0: 1, 1: 2, 2: 3}
+
+
+class NsevOpts(C.Structure):
+    """fnft_nsev_opts_t, include/fnft_nsev.h:198-208 (same field order = same ABI)."""
+    _fields_ = [
+        ("bound_state_filtering", C.c_int),
+        ("bound_state_localization", C.c_int),
+        ("niter", C.c_size_t),
+        ("Dsub", C.c_size_t),
+        ("discspec_type", C.c_int),
+        ("contspec_type", C.c_int),
+        ("normalization_flag", C.c_int32),
+        ("discretization", C.c_int),
+        ("richardson_extrapolation_flag", C.c_size_t),
+    ]
+
+
+PRINTF_T = C.CFUNCTYPE(C.c_int32, C.c_char_p)  # variadic in C; used only to silence output
+
+EXPORTED = [
+    "fnft_nsev", "fnft_nsev_default_opts", "fnft_nsev_max_K", "fnft_errwarn_setprintf",
+    "fnft_errwarn_getprintf", "fnft__poly_fmult2x2_numel", "fnft__poly_fmult2x2",
+    "fnft_amd_poly_chirpz", "fnft__poly_chirpz", "fnft__akns_fscatter_numel", "fnft__akns_fscatter",
+    "fnft__nse_fscatter_numel", "fnft__nse_fscatter", "fnft_amd_device_count",
+    "fnft_amd_last_error", "fnft_amd_plan_create", "fnft_amd_plan_destroy",
+    "fnft_amd_plan_workspace_bytes", "fnft_amd_nsev_contspec_device", "fnft_amd_plan_finish",
+    "fnft_amd_plan_last_ms", "fnft_amd_plan_set_timing", "fnft_amd_plan_get_transfer_matrix",
+]
+
+_lib = None
+
+
+def load(path=None):
+    """Load libfnft_amd.so.  Raises (never falls back) when the library is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "libfnft_amd.so not found at %s -- run `python -m fnft_amd.build` (hipcc, gfx950); "
+            "this package has no CPU fallback" % p)
+    L = C.CDLL(p)
+    vp, sz, i32, dbl = C.c_void_p, C.c_size_t, C.c_int32, C.c_double
+    L.fnft_nsev_default_opts.restype = NsevOpts
+    L.fnft_nsev_default_opts.argtypes = []
+    L.fnft_nsev_max_K.restype = sz
+    L.fnft_nsev_max_K.argtypes = [sz, C.POINTER(NsevOpts)]
+    L.fnft_nsev.restype = i32
+    L.fnft_nsev.argtypes = [sz, vp, vp, sz, vp, vp, C.POINTER(sz), vp, vp, i32, C.POINTER(NsevOpts)]
+    L.fnft_errwarn_setprintf.restype = None
+    L.fnft_errwarn_setprintf.argtypes = [vp]
+    L.fnft_errwarn_getprintf.restype = vp
+    L.fnft__poly_fmult2x2_numel.restype = sz
+    L.fnft__poly_fmult2x2_numel.argtypes = [sz, sz]
+    L.fnft__poly_fmult2x2.restype = i32
+    L.fnft__poly_fmult2x2.argtypes = [C.POINTER(sz), sz, vp, vp, C.POINTER(i32)]
+    L.fnft_amd_poly_chirpz.restype = i32
+    L.fnft_amd_poly_chirpz.argtypes = [sz, vp, C.POINTER(dbl), C.POINTER(dbl), sz, vp]
+    L.fnft__akns_fscatter_numel.restype = sz
+    L.fnft__akns_fscatter_numel.argtypes = [sz, C.c_int]
+    L.fnft__akns_fscatter.restype = i32
+    L.fnft__akns_fscatter.argtypes = [sz, vp, vp, dbl, vp, C.POINTER(sz), C.POINTER(i32), C.c_int]
+    L.fnft__nse_fscatter_numel.restype = sz
+    L.fnft__nse_fscatter_numel.argtypes = [sz, C.c_int]
+    L.fnft__nse_fscatter.restype = i32
+    L.fnft__nse_fscatter.argtypes = [sz, vp, dbl, i32, vp, C.POINTER(sz), C.POINTER(i32), C.c_int]
+    L.fnft_amd_device_count.restype = C.c_int
+    L.fnft_amd_last_error.restype = C.c_char_p
+    L.fnft_amd_plan_create.restype = i32
+    L.fnft_amd_plan_create.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int]
+    L.fnft_amd_plan_destroy.restype = None
+    L.fnft_amd_plan_destroy.argtypes = [vp]
+    L.fnft_amd_plan_workspace_bytes.restype = sz
+    L.fnft_amd_plan_workspace_bytes.argtypes = [vp]
+    L.fnft_amd_nsev_contspec_device.restype = i32
+    L.fnft_amd_nsev_contspec_device.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl), i32,
+                                                C.c_int, i32, vp]
+    L.fnft_amd_plan_finish.restype = i32
+    L.fnft_amd_plan_finish.argtypes = [vp, vp]
+    L.fnft_amd_plan_last_ms.restype = dbl
+    L.fnft_amd_plan_last_ms.argtypes = [vp, C.c_int]
+    L.fnft_amd_plan_set_timing.restype = None
+    L.fnft_amd_plan_set_timing.argtypes = [vp, C.c_int]
+    L.fnft_amd_plan_get_transfer_matrix.restype = i32
+    L.fnft_amd_plan_get_transfer_matrix.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(i32)]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _d2(v):
+    return (C.c_double * 2)(float(v[0]), float(v[1]))
+
+
+def last_error():
+    return load().fnft_amd_last_error().decode()
+
+
+def silence_errors(lib=None):
+    """fnft_errwarn_setprintf(NULL): the reference's way of disabling error text."""
+    (lib or load()).fnft_errwarn_setprintf(None)
+
+
+def default_opts():
+    return load().fnft_nsev_default_opts()
+
+
+# --------------------------------------------------------------------------------------------
+# host-pointer calls (drop-in boundary)
+# --------------------------------------------------------------------------------------------
+def fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="REFLECTION_COEFFICIENT",
+              normalization_flag=1, opts=None, want_contspec=True, bound_states=None, K=None):
+    """fnft_nsev() through the C ABI with host (numpy) buffers.  Returns (rc, contspec)."""
+    L = load()
+    q = _c128(q)
+    if opts is None:
+        opts = L.fnft_nsev_default_opts()
+        opts.discretization = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+        opts.contspec_type = CSTYPE[contspec_type] if isinstance(contspec_type, str) else int(contspec_type)
+        opts.normalization_flag = int(normalization_flag)
+    Tn = None if T is None else np.ascontiguousarray(T, np.float64)
+    XIn = None if XI is None else np.ascontiguousarray(XI, np.float64)
+    fac = CS_FACTOR.get(int(opts.contspec_type), 3)
+    cs = np.zeros(max(M * fac, 1), np.complex128) if want_contspec else None
+    Kc = C.c_size_t(K if K is not None else 0)
+    rc = L.fnft_nsev(q.size, _ptr(q), None if Tn is None else _ptr(Tn), M,
+                     None if cs is None else _ptr(cs), None if XIn is None else _ptr(XIn),
+                     C.byref(Kc) if K is not None else None,
+                     None if bound_states is None else _ptr(bound_states), None, int(kappa),
+                     C.byref(opts))
+    return int(rc), (cs[: M * fac] if cs is not None else None)
+
+
+def poly_fmult2x2(deg, n, p, normalize=True):
+    """fnft__poly_fmult2x2: p[4, n*(deg+1)] -> (rc, deg_out, result[4, deg_out+1], W)."""
+    L = load()
+    numel = int(L.fnft__poly_fmult2x2_numel(deg, n))
+    buf = np.zeros(max(numel, 1), np.complex128)
+    p = _c128(p).ravel()
+    buf[: p.size] = p
+    res = np.zeros(max(numel, 1), np.complex128)
+    d = C.c_size_t(deg)
+    W = C.c_int32(0)
+    rc = L.fnft__poly_fmult2x2(C.byref(d), n, _ptr(buf), _ptr(res), C.byref(W) if normalize else None)
+    dd = d.value
+    return int(rc), dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
+
+
+def poly_chirpz(p, A, W, M):
+    L = load()
+    p = _c128(p)
+    out = np.zeros(M, np.complex128)
+    A, W = complex(A), complex(W)
+    rc = L.fnft_amd_poly_chirpz(p.size - 1, _ptr(p), _d2((A.real, A.imag)), _d2((W.real, W.imag)), M,
+                                _ptr(out))
+    return int(rc), out
+
+
+def akns_fscatter(q, r, eps_t, discretization, normalize=True):
+    L = load()
+    q, r = _c128(q), _c128(r)
+    a = AKNS_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    numel = int(L.fnft__akns_fscatter_numel(q.size, a))
+    res = np.zeros(max(numel, 1), np.complex128)
+    d = C.c_size_t(0)
+    W = C.c_int32(0)
+    rc = L.fnft__akns_fscatter(q.size, _ptr(q), _ptr(r), eps_t, _ptr(res), C.byref(d),
+                               C.byref(W) if normalize else None, a)
+    dd = d.value
+    return int(rc), dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
+
+
+def nse_fscatter(q, eps_t, kappa, discretization, normalize=True):
+    L = load()
+    q = _c128(q)
+    n = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    numel = int(L.fnft__nse_fscatter_numel(q.size, n))
+    res = np.zeros(max(numel, 1), np.complex128)
+    d = C.c_size_t(0)
+    W = C.c_int32(0)
+    rc = L.fnft__nse_fscatter(q.size, _ptr(q), eps_t, int(kappa), _ptr(res), C.byref(d),
+                              C.byref(W) if normalize else None, n)
+    dd = d.value
+    return int(rc), dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
+
+
+# --------------------------------------------------------------------------------------------
+# device-resident plan (inputs already in HBM)
+# --------------------------------------------------------------------------------------------
+class Plan:
+    """fnft_amd_plan_t: `batch` signals of D samples, M spectral points, one discretization."""
+
+    def __init__(self, D, M, batch=1, discretization="2SPLIT2_MODAL", device=0):
+        self.L = load()
+        self.D, self.M, self.batch = int(D), int(M), int(batch)
+        self.disc = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+        self.h = C.c_void_p()
+        rc = self.L.fnft_amd_plan_create(C.byref(self.h), self.D, self.M, self.batch, self.disc,
+                                         int(device))
+        if rc != FNFT_SUCCESS:
+            raise RuntimeError("fnft_amd_plan_create rc=%d (%s)" % (rc, last_error()))
+
+    def close(self):
+        if self.h:
+            self.L.fnft_amd_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self.L.fnft_amd_plan_workspace_bytes(self.h))
+
+    def cs_len(self, contspec_type):
+        c = CSTYPE[contspec_type] if isinstance(contspec_type, str) else int(contspec_type)
+        return self.M * CS_FACTOR[c]
+
+    def set_timing(self, on=True):
+        self.L.fnft_amd_plan_set_timing(self.h, 1 if on else 0)
+
+    def last_ms(self, which=2):
+        return float(self.L.fnft_amd_plan_last_ms(self.h, which))
+
+    def contspec_device(self, q_ptr, out_ptr, T, XI, kappa=1, contspec_type="BOTH",
+                        normalization_flag=1, stream=0):
+        """Enqueue one pass.  q_ptr/out_ptr are raw device addresses (e.g. tensor.data_ptr())."""
+        c = CSTYPE[contspec_type] if isinstance(contspec_type, str) else int(contspec_type)
+        return int(self.L.fnft_amd_nsev_contspec_device(
+            self.h, C.c_void_p(q_ptr), C.c_void_p(out_ptr), _d2(T), _d2(XI), int(kappa), c,
+            int(normalization_flag), C.c_void_p(stream)))
+
+    def finish(self, stream=0):
+        return int(self.L.fnft_amd_plan_finish(self.h, C.c_void_p(stream)))
+
+    def transfer_matrix(self, b=0):
+        deg = C.c_size_t(0)
+        W = C.c_int32(0)
+        # deg is D*deg0; allocate for the largest supported deg0 = 4
+        buf = np.zeros(4 * (4 * self.D + 1), np.complex128)
+        rc = self.L.fnft_amd_plan_get_transfer_matrix(self.h, b, _ptr(buf), C.byref(deg), C.byref(W))
+        d = deg.value
+        return int(rc), d, buf[: 4 * (d + 1)].reshape(4, d + 1).copy(), int(W.value)

@@ -1,0 +1,65 @@
+// dev_compat.h -- the thin layer that lets the kernel bodies in this directory be compiled
+//   (a) by hipcc for gfx950 (the product), and
+//   (b) by g++ into the thread-per-lane CPU emulator under tests/emu/ (test infrastructure only,
+//       used to check index arithmetic without a GPU; never linked into libfnft_amd.so).
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define FA_HD __host__ __device__ __forceinline__
+#define FA_DEV __device__ __forceinline__
+#define FA_KERNEL __global__
+#define FA_SYNC() __syncthreads()
+#define FA_TID ((int)threadIdx.x)
+#define FA_BID ((int)blockIdx.x)
+#define FA_BID_Y ((int)blockIdx.y)
+#define FA_BDIM ((int)blockDim.x)
+#define FA_GDIM ((int)gridDim.x)
+// dynamic LDS: one extern array per kernel translation unit
+#define FA_LDS_DECL extern __shared__ __attribute__((aligned(16))) unsigned char fa_lds_raw[];
+#define FA_LDS_PTR (fa_lds_raw)
+FA_DEV void fa_atomic_max_u64(unsigned long long *p, unsigned long long v) { atomicMax(p, v); }
+FA_DEV void fa_atomic_add_i32(int *p, int v) { atomicAdd(p, v); }
+FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
+FA_DEV void fa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+#else
+// ------------------------------------------------------------------------------------------
+#include <barrier>
+#include <cmath>
+#define FA_HD inline
+#define FA_DEV inline
+#define FA_KERNEL
+struct fa_emu_ctx {
+    int tid, bid, bid_y, bdim, gdim;
+    std::barrier<> *bar;
+    unsigned char *lds;
+};
+extern thread_local fa_emu_ctx *fa_emu;
+#define FA_SYNC() fa_emu->bar->arrive_and_wait()
+#define FA_TID (fa_emu->tid)
+#define FA_BID (fa_emu->bid)
+#define FA_BID_Y (fa_emu->bid_y)
+#define FA_BDIM (fa_emu->bdim)
+#define FA_GDIM (fa_emu->gdim)
+#define FA_LDS_DECL
+#define FA_LDS_PTR (fa_emu->lds)
+#define __restrict__
+FA_DEV void fa_atomic_max_u64(unsigned long long *p, unsigned long long v)
+{
+    unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+FA_DEV void fa_atomic_add_i32(int *p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
+using std::exp;
+using std::floor;
+using std::fma;
+using std::ldexp;
+using std::log2;
+using std::sqrt;
+#endif

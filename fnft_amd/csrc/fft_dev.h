@@ -1,0 +1,208 @@
+// fft_dev.h -- fp64 complex arithmetic, in-register DFTs and the workgroup-cooperative Stockham
+// FFT every kernel of the product tree and of the chirp z-transform is built from.
+//
+// Replaces the reference's KissFFT back end (src/3rd_party/kiss_fft/kiss_fft.c:237-302 via
+// include/private/fnft__fft_wrapper.h:124-137).  Semantics are the same (unnormalised, sign -1
+// forward / +1 inverse); lengths are powers of two (any length >= the linear convolution length
+// gives the same polynomial product).
+//
+// Design (CDNA4): each lane keeps R points in VGPRs, a radix-R butterfly is pure register work,
+// and lanes exchange points through LDS once per pass (Stockham autosort, so every LDS read is
+// lane-contiguous 16-byte ds_read_b128).  B independent transforms are interleaved with the
+// batch index fastest, which keeps LDS accesses conflict-free for the small transforms of the
+// lower tree levels.
+#pragma once
+#include "dev_compat.h"
+
+struct __attribute__((aligned(16))) cplx {
+    double x, y;
+};
+
+FA_HD cplx cmake(double x, double y) { cplx r; r.x = x; r.y = y; return r; }
+FA_HD cplx operator+(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+FA_HD cplx operator-(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+FA_HD cplx operator*(cplx a, cplx b)
+{
+    return cmake(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+FA_HD cplx operator*(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+FA_HD cplx cconj(cplx a) { return cmake(a.x, -a.y); }
+// c + a*b
+FA_HD cplx cfma(cplx a, cplx b, cplx c)
+{
+    return cmake(fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y)));
+}
+FA_HD double cnorm2(cplx a) { return fma(a.x, a.x, a.y * a.y); }
+
+// a * (SIGN * i)
+template <int SIGN> FA_HD cplx mul_si(cplx a)
+{
+    return SIGN > 0 ? cmake(-a.y, a.x) : cmake(a.y, -a.x);
+}
+// conj for the inverse direction: tables hold exp(-2 pi i j / n)
+template <int SIGN> FA_HD cplx tw_dir(cplx w) { return SIGN > 0 ? cconj(w) : w; }
+
+// ---------------------------------------------------------------------------------------------
+// In-register DFTs, natural order in and out:  X[k] = sum_j x[j] exp(SIGN*2*pi*i*j*k/R)
+// ---------------------------------------------------------------------------------------------
+template <int R, int SIGN> struct RegDft;
+
+template <int SIGN> struct RegDft<1, SIGN> {
+    static FA_HD void run(cplx (&)[1]) {}
+};
+
+template <int SIGN> struct RegDft<2, SIGN> {
+    static FA_HD void run(cplx (&x)[2])
+    {
+        cplx a = x[0], b = x[1];
+        x[0] = a + b;
+        x[1] = a - b;
+    }
+};
+
+template <int SIGN> struct RegDft<4, SIGN> {
+    static FA_HD void run(cplx (&x)[4])
+    {
+        cplx s0 = x[0] + x[2], d0 = x[0] - x[2];
+        cplx s1 = x[1] + x[3], d1 = mul_si<SIGN>(x[1] - x[3]);
+        x[0] = s0 + s1;
+        x[1] = d0 + d1;
+        x[2] = s0 - s1;
+        x[3] = d0 - d1;
+    }
+};
+
+template <int SIGN> struct RegDft<8, SIGN> {
+    static FA_HD void run(cplx (&x)[8])
+    {
+        const double h = 0.70710678118654752440;
+        cplx e[4], o[4];
+        for (int k = 0; k < 4; k++) e[k] = x[k] + x[k + 4];
+        cplx t0 = x[0] - x[4], t1 = x[1] - x[5], t2 = x[2] - x[6], t3 = x[3] - x[7];
+        const double S = (double)SIGN;
+        o[0] = t0;
+        o[1] = cmake(h * (t1.x - S * t1.y), h * (S * t1.x + t1.y));   // * w8^1 = h(1 + S i)
+        o[2] = mul_si<SIGN>(t2);                                      // * w8^2 = S i
+        o[3] = cmake(h * (-t3.x - S * t3.y), h * (S * t3.x - t3.y));  // * w8^3 = h(-1 + S i)
+        RegDft<4, SIGN>::run(e);
+        RegDft<4, SIGN>::run(o);
+        for (int k = 0; k < 4; k++) {
+            x[2 * k] = e[k];
+            x[2 * k + 1] = o[k];
+        }
+    }
+};
+
+template <int SIGN> struct RegDft<16, SIGN> {
+    static FA_HD void run(cplx (&x)[16])
+    {
+        // w16^k = cos(k pi/8) + S i sin(k pi/8)
+        const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;
+        const double h = 0.70710678118654752440;
+        const double S = (double)SIGN;
+        cplx e[8], o[8];
+        for (int k = 0; k < 8; k++) {
+            e[k] = x[k] + x[k + 8];
+            o[k] = x[k] - x[k + 8];
+        }
+        o[1] = o[1] * cmake(c1, S * s1);
+        o[2] = o[2] * cmake(h, S * h);
+        o[3] = o[3] * cmake(s1, S * c1);
+        o[4] = mul_si<SIGN>(o[4]);
+        o[5] = o[5] * cmake(-s1, S * c1);
+        o[6] = o[6] * cmake(-h, S * h);
+        o[7] = o[7] * cmake(-c1, S * s1);
+        RegDft<8, SIGN>::run(e);
+        RegDft<8, SIGN>::run(o);
+        for (int k = 0; k < 8; k++) {
+            x[2 * k] = e[k];
+            x[2 * k + 1] = o[k];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup-cooperative FFT of B interleaved length-N sequences, R points per lane.
+//
+// Lane (v, c), v < N/R, c < B, owns the elements  v + (N/R)*i,  i < R  of sequence c, both on
+// entry and on exit (natural order).  Stockham decimation-in-frequency pass of radix r on
+// n_cur-point sub-problems with s = N/n_cur finished sub-transforms:
+//     y[q + s*(r*p + k)] = w_{n_cur}^{p k} * DFT_r( x[q + s*(p + m*j)] )_k,   m = n_cur/r,
+// for butterfly u = q + s*p; its inputs are x[u + (N/r)*j] -- registers j' + (R/r)*j of the lane
+// that owns u -- so only the outputs cross lanes (through LDS).  The last pass (n_cur == r)
+// writes to the positions it read, so its results stay in registers.
+//
+// tw: table of exp(-2*pi*i*j/N), j < N (forward); the inverse direction conjugates.
+// lds: DB = true: 2 buffers of N*B elements each; `parity` selects the next buffer to write and
+// must be carried across consecutive calls (one barrier per exchange is then sufficient).
+// DB = false: one buffer, two barriers per exchange.
+// ---------------------------------------------------------------------------------------------
+template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S> struct FftPass {
+    static constexpr int r = (NCUR < R) ? NCUR : R;
+    static constexpr int J = R / r;     // butterflies per lane
+    static constexpr int m = NCUR / r;
+    static constexpr bool last = (NCUR == r);
+
+    static FA_DEV void run(cplx (&x)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw,
+                           int &parity)
+    {
+        cplx *buf = DB ? lds + (size_t)parity * (size_t)(N * B) : lds;
+        if constexpr (!last && !DB) FA_SYNC();  // single buffer: previous readers must be done
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int u = v + (N / R) * j;
+            const int q = u % S;
+            const int p = u / S;
+            cplx t[r];
+#pragma unroll
+            for (int k = 0; k < r; k++) t[k] = x[j + J * k];
+            RegDft<r, SIGN>::run(t);
+            if constexpr (!last) {
+#pragma unroll
+                for (int k = 1; k < r; k++) t[k] = t[k] * tw_dir<SIGN>(tw[(size_t)(p * k) * S]);
+#pragma unroll
+                for (int k = 0; k < r; k++) buf[(size_t)(q + S * (r * p + k)) * B + c] = t[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < r; k++) x[j + J * k] = t[k];
+            }
+        }
+        if constexpr (!last) {
+            FA_SYNC();
+#pragma unroll
+            for (int i = 0; i < R; i++) x[i] = buf[(size_t)(v + (N / R) * i) * B + c];
+            parity ^= 1;
+            FftPass<N, R, B, SIGN, DB, NCUR / r, S * r>::run(x, lds, v, c, tw, parity);
+        }
+    }
+};
+
+template <int N, int R, int B, int SIGN, bool DB, int S> struct FftPass<N, R, B, SIGN, DB, 1, S> {
+    static FA_DEV void run(cplx (&)[R], cplx *, int, int, const cplx *__restrict__, int &) {}
+};
+
+template <int N, int R, int B, int SIGN, bool DB = true>
+FA_DEV void fft_wg(cplx (&x)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw, int &parity)
+{
+    static_assert(N >= R, "fft_wg: N must be at least R");
+    FftPass<N, R, B, SIGN, DB, N, 1>::run(x, lds, v, c, tw, parity);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exp(-2*pi*i*j/N) for any power of two N <= NMAX = 2^(2*FINE) from one pair of master tables:
+//   J = j * (NMAX/N) = jh*2^FINE + jl,   w = hi[jh] * lo[jl],
+//   hi[jh] = exp(-2 pi i jh / 2^FINE),   lo[jl] = exp(-2 pi i jl / NMAX).
+// ---------------------------------------------------------------------------------------------
+struct BigTwiddle {
+    const cplx *hi;
+    const cplx *lo;
+    int fine_log2;  // FINE
+    int shift;      // log2(NMAX/N)
+};
+FA_DEV cplx big_twiddle(const BigTwiddle &t, unsigned j)
+{
+    const unsigned J = j << t.shift;
+    const cplx a = t.hi[J >> t.fine_log2];
+    const cplx b = t.lo[J & ((1u << t.fine_log2) - 1u)];
+    return a * b;
+}

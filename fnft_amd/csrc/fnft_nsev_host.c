@@ -1,0 +1,209 @@
+/*
+ * fnft_nsev_host.c -- the C driver behind the drop-in symbols of include/fnft_amd.h section 1.
+ *
+ * Mirrors the argument handling of the reference's src/fnft_nsev.c:133-453 (validation order,
+ * return codes, option defaults, message format of src/private/fnft__errwarn.c:28-46) and hands
+ * the numerical work to the HIP shim (hip_backend.hip).  There is no CPU fallback: without a
+ * usable GPU the call fails with FNFT_EC_OTHER and an error message.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/fnft_amd.h"
+
+/* version of the interface this library stands in for (CMakeLists.txt:22-25 of the reference) */
+#define FNFT_AMD_IFACE_MAJOR 0
+#define FNFT_AMD_IFACE_MINOR 4
+#define FNFT_AMD_IFACE_PATCH 1
+#define FNFT_AMD_IFACE_SUFFIX "+amd"
+
+/* HIP shim */
+FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const FNFT_REAL *T,
+                                      FNFT_UINT M, FNFT_COMPLEX *contspec, const FNFT_REAL *XI,
+                                      FNFT_INT kappa, int discretization, int contspec_type,
+                                      FNFT_INT normalization_flag);
+
+/* ---- error / warning text, src/fnft_errwarn.c:28-60 ---------------------------------------- */
+static FNFT_INT default_printf(const char *format, ...)
+{
+    va_list args;
+    va_start(args, format);
+    const int rc = vfprintf(stderr, format, args);
+    va_end(args);
+    return rc;
+}
+
+static _Thread_local fnft_printf_ptr_t printf_ptr = default_printf;
+
+void fnft_errwarn_setprintf(fnft_printf_ptr_t p) { printf_ptr = p; }
+fnft_printf_ptr_t fnft_errwarn_getprintf(void) { return printf_ptr; }
+
+static FNFT_INT raise(FNFT_INT ec, const char *func, int line, const char *msg)
+{
+    fnft_printf_ptr_t p = fnft_errwarn_getprintf();
+    if (p != NULL)
+        p("FNFT Error: %s\n in %s(%i)-%d.%d.%d%s\n", msg, func, line, FNFT_AMD_IFACE_MAJOR,
+          FNFT_AMD_IFACE_MINOR, FNFT_AMD_IFACE_PATCH, FNFT_AMD_IFACE_SUFFIX);
+    return ec;
+}
+#define E_INVALID_ARGUMENT(name) raise(FNFT_EC_INVALID_ARGUMENT, __func__, __LINE__, "Invalid argument " #name ".")
+#define E_NOT_YET_IMPLEMENTED(name, msg) \
+    raise(FNFT_EC_NOT_YET_IMPLEMENTED, __func__, __LINE__, "Not yet implemented (" #name "). " msg)
+#define E_SUBROUTINE(ec) raise(-abs(ec), __func__, __LINE__, "Subroutine failure.")
+
+/* ---- defaults, src/fnft_nsev.c:26-45 --------------------------------------------------------- */
+static fnft_nsev_opts_t default_opts = {
+    .bound_state_filtering = fnft_nsev_bsfilt_FULL,
+    .bound_state_localization = fnft_nsev_bsloc_SUBSAMPLE_AND_REFINE,
+    .niter = 10,
+    .Dsub = 0,
+    .discspec_type = fnft_nsev_dstype_NORMING_CONSTANTS,
+    .contspec_type = fnft_nsev_cstype_REFLECTION_COEFFICIENT,
+    .normalization_flag = 1,
+    .discretization = fnft_nse_discretization_2SPLIT4B,
+    .richardson_extrapolation_flag = 0};
+
+fnft_nsev_opts_t fnft_nsev_default_opts(void) { return default_opts; }
+
+/* degree of one step, src/private/fnft__akns_discretization.c:29-67 via nse->akns mapping;
+ * 0 for the slow (non-polynomial) discretizations */
+static FNFT_UINT nse_degree(fnft_nse_discretization_t d)
+{
+    switch (d) {
+    case fnft_nse_discretization_2SPLIT2_MODAL:
+    case fnft_nse_discretization_2SPLIT1A:
+    case fnft_nse_discretization_2SPLIT1B:
+    case fnft_nse_discretization_2SPLIT2A:
+    case fnft_nse_discretization_2SPLIT2B:
+    case fnft_nse_discretization_2SPLIT2S: return 1;
+    case fnft_nse_discretization_2SPLIT3S:
+    case fnft_nse_discretization_2SPLIT4B:
+    case fnft_nse_discretization_4SPLIT4B: return 2;
+    case fnft_nse_discretization_2SPLIT3A:
+    case fnft_nse_discretization_2SPLIT3B: return 3;
+    case fnft_nse_discretization_2SPLIT4A:
+    case fnft_nse_discretization_4SPLIT4A: return 4;
+    case fnft_nse_discretization_2SPLIT6B: return 6;
+    case fnft_nse_discretization_2SPLIT6A:
+    case fnft_nse_discretization_2SPLIT8B: return 12;
+    case fnft_nse_discretization_2SPLIT5A:
+    case fnft_nse_discretization_2SPLIT5B: return 15;
+    case fnft_nse_discretization_2SPLIT8A: return 24;
+    case fnft_nse_discretization_2SPLIT7A:
+    case fnft_nse_discretization_2SPLIT7B: return 105;
+    default: return 0;
+    }
+}
+
+/* src/fnft_nsev.c:51-57 */
+FNFT_UINT fnft_nsev_max_K(const FNFT_UINT D, fnft_nsev_opts_t const *const opts)
+{
+    if (opts != NULL) return nse_degree(opts->discretization) * D;
+    return nse_degree(default_opts.discretization) * D;
+}
+
+/* include/fnft_nsev.h:371-376, src/fnft_nsev.c:133-453 */
+FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *const T,
+                   const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI,
+                   FNFT_UINT *const K_ptr, FNFT_COMPLEX *const bound_states,
+                   FNFT_COMPLEX *const normconsts_or_residues, const FNFT_INT kappa,
+                   fnft_nsev_opts_t *opts)
+{
+    FNFT_INT ret_code = FNFT_SUCCESS;
+    (void)normconsts_or_residues;
+
+    /* same checks, same order as src/fnft_nsev.c:163-180 */
+    if (D < 2) return E_INVALID_ARGUMENT(D);
+    if (q == NULL) return E_INVALID_ARGUMENT(q);
+    if (T == NULL || T[0] >= T[1]) return E_INVALID_ARGUMENT(T);
+    if (contspec != NULL) {
+        if (XI == NULL || XI[0] >= XI[1]) return E_INVALID_ARGUMENT(XI);
+    }
+    if (abs(kappa) != 1) return E_INVALID_ARGUMENT(kappa);
+    if (bound_states != NULL) {
+        if (K_ptr == NULL) return E_INVALID_ARGUMENT(K_ptr);
+    }
+    if (opts == NULL) opts = &default_opts;
+
+    /* src/fnft_nsev.c:183-220 */
+    switch (opts->discretization) {
+    case fnft_nse_discretization_2SPLIT2_MODAL:
+    case fnft_nse_discretization_2SPLIT1A:
+    case fnft_nse_discretization_2SPLIT1B:
+    case fnft_nse_discretization_2SPLIT2A:
+    case fnft_nse_discretization_2SPLIT2B:
+    case fnft_nse_discretization_2SPLIT2S:
+    case fnft_nse_discretization_2SPLIT3S:
+    case fnft_nse_discretization_2SPLIT4B:
+    case fnft_nse_discretization_2SPLIT3A:
+    case fnft_nse_discretization_2SPLIT3B:
+    case fnft_nse_discretization_2SPLIT4A:
+    case fnft_nse_discretization_2SPLIT6B:
+    case fnft_nse_discretization_2SPLIT6A:
+    case fnft_nse_discretization_2SPLIT8B:
+    case fnft_nse_discretization_2SPLIT5A:
+    case fnft_nse_discretization_2SPLIT5B:
+    case fnft_nse_discretization_2SPLIT8A:
+    case fnft_nse_discretization_2SPLIT7A:
+    case fnft_nse_discretization_2SPLIT7B:
+    case fnft_nse_discretization_4SPLIT4A:
+    case fnft_nse_discretization_4SPLIT4B:
+        break;
+    case fnft_nse_discretization_BO:
+    case fnft_nse_discretization_CF4_2:
+    case fnft_nse_discretization_CF4_3:
+    case fnft_nse_discretization_CF5_3:
+    case fnft_nse_discretization_CF6_4:
+    case fnft_nse_discretization_ES4:
+    case fnft_nse_discretization_TES4:
+        if (opts->bound_state_localization != fnft_nsev_bsloc_NEWTON && kappa == +1)
+            return E_INVALID_ARGUMENT(opts->bound_state_localization);
+        break;
+    default:
+        return E_INVALID_ARGUMENT(opts->discretization);
+    }
+
+    /* what this build does not cover yet is reported, never silently approximated */
+    switch (opts->discretization) {
+    case fnft_nse_discretization_2SPLIT2_MODAL:
+    case fnft_nse_discretization_2SPLIT1A:
+    case fnft_nse_discretization_2SPLIT1B:
+    case fnft_nse_discretization_2SPLIT2A:
+    case fnft_nse_discretization_2SPLIT2B:
+    case fnft_nse_discretization_2SPLIT2S:
+    case fnft_nse_discretization_2SPLIT3A:
+    case fnft_nse_discretization_2SPLIT3B:
+    case fnft_nse_discretization_2SPLIT3S:
+    case fnft_nse_discretization_2SPLIT4A:
+    case fnft_nse_discretization_2SPLIT4B:
+        break;
+    default:
+        return E_NOT_YET_IMPLEMENTED(discretization,
+                                     "GPU path covers the 2SPLIT schemes of degree <= 4.");
+    }
+    if (kappa == +1 && bound_states != NULL)
+        return E_NOT_YET_IMPLEMENTED(bound_states, "Pass bound_states = NULL for the continuous spectrum.");
+    if (opts->richardson_extrapolation_flag == 1)
+        return E_NOT_YET_IMPLEMENTED(richardson_extrapolation_flag, "Richardson extrapolation.");
+    if (contspec != NULL && M > 0) {
+        const int cst = (int)opts->contspec_type;
+        if (cst < 0 || cst > 2) { /* src/fnft_nsev.c:880-883, raised inside nsev_compute_contspec */
+            ret_code = E_INVALID_ARGUMENT(opts->contspec_type);
+            ret_code = E_SUBROUTINE(ret_code);
+            return E_SUBROUTINE(ret_code);
+        }
+    }
+
+    ret_code = fnft_amd__nsev_contspec_host(D, q, T, (contspec != NULL) ? M : 0, contspec, XI, kappa,
+                                            (int)opts->discretization, (int)opts->contspec_type,
+                                            opts->normalization_flag);
+    if (ret_code != FNFT_SUCCESS) {
+        if (ret_code == FNFT_EC_OTHER || ret_code == FNFT_EC_NOMEM)
+            return raise(ret_code, __func__, __LINE__, "GPU runtime failure (see fnft_amd_last_error()).");
+        return E_SUBROUTINE(ret_code);
+    }
+    /* src/fnft_nsev.c:558-560: no discrete spectrum was computed */
+    if (K_ptr != NULL) *K_ptr = 0;
+    return FNFT_SUCCESS;
+}

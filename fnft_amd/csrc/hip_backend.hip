@@ -1,0 +1,374 @@
+// hip_backend.hip -- the HIP side of libfnft_amd.so: kernel entry template, HIP back end for
+// NftPlan, and the extern "C" shim (sections 2 and 3 of include/fnft_amd.h plus the internal
+// entry the C driver fnft_nsev_host.c calls).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <type_traits>
+
+#include "nft_api.h"
+#include "../../include/fnft_amd.h"
+
+static thread_local std::string g_last_error;
+
+static bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+template <class K, class = void> struct min_waves_of { static constexpr int value = 1; };
+template <class K> struct min_waves_of<K, std::void_t<decltype(K::MIN_WAVES)>> {
+    static constexpr int value = K::MIN_WAVES;
+};
+
+template <class K>
+__global__ void __launch_bounds__(K::THREADS, min_waves_of<K>::value)
+kernel_entry(const typename K::Params p)
+{
+    K::body(p);
+}
+
+struct HipBackend {
+    hipStream_t stream = nullptr;
+    bool failed = false;
+    // stage timers
+    static constexpr int kMarks = 4;
+    hipEvent_t ev[kMarks] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing = false;
+
+    void *alloc(size_t b)
+    {
+        void *p = nullptr;
+        if (!hip_ok(hipMalloc(&p, b), "hipMalloc")) { failed = true; return nullptr; }
+        return p;
+    }
+    void free(void *p) { if (p) (void)hipFree(p); }
+    void h2d(void *d, const void *s, size_t b)
+    {
+        // pageable source: make the copy complete before the caller's buffer can go away
+        if (!hip_ok(hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(H2D)")) failed = true;
+        if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) failed = true;
+    }
+    void d2h(void *d, const void *s, size_t b)
+    {
+        if (!hip_ok(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(D2H)")) failed = true;
+    }
+    void memset0(void *d, size_t b)
+    {
+        if (!hip_ok(hipMemsetAsync(d, 0, b, stream), "hipMemsetAsync")) failed = true;
+    }
+    int sync()
+    {
+        if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) failed = true;
+        return failed ? NFT_EC_OTHER : NFT_SUCCESS;
+    }
+    void mark(int i)
+    {
+        if (!timing) return;
+        if (!ev[i]) (void)hipEventCreate(&ev[i]);
+        (void)hipEventRecord(ev[i], stream);
+    }
+    double elapsed_ms(int i0, int i1) const
+    {
+        if (!timing || !ev[i0] || !ev[i1]) return -1.0;
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, ev[i0], ev[i1]) != hipSuccess) return -1.0;
+        return (double)ms;
+    }
+    void destroy_events()
+    {
+        for (int i = 0; i < kMarks; i++)
+            if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+    }
+
+    template <class K> void run(int gx, int gy, const typename K::Params &p)
+    {
+        constexpr size_t lds = K::lds_bytes();
+        static bool attr_done = false;  // one flag per kernel instantiation
+        if (lds > 48 * 1024 && !attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kernel_entry<K>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        if (gx <= 0 || gy <= 0) return;
+        hipLaunchKernelGGL(kernel_entry<K>, dim3((unsigned)gx, (unsigned)gy), dim3(K::THREADS), lds,
+                           stream, p);
+        if (!hip_ok(hipGetLastError(), "kernel launch")) failed = true;
+    }
+};
+
+using Plan = NftPlan<HipBackend>;
+
+struct fnft_amd_plan {
+    HipBackend be;
+    Plan *pl = nullptr;
+    int device = 0;
+    int nse_disc = 0;
+    std::mutex mtx;
+};
+
+static bool ensure_device(int device)
+{
+    int n = 0;
+    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
+        if (g_last_error.empty()) g_last_error = "no HIP device";
+        return false;
+    }
+    if (device < 0 || device >= n) { g_last_error = "device index out of range"; return false; }
+    return hip_ok(hipSetDevice(device), "hipSetDevice");
+}
+
+extern "C" {
+
+int fnft_amd_device_count(void)
+{
+    int n = 0;
+    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount")) return -1;
+    return n;
+}
+
+const char *fnft_amd_last_error(void) { return g_last_error.c_str(); }
+
+FNFT_INT fnft_amd_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
+                              fnft_nse_discretization_t discretization, int device)
+{
+    if (!plan || D < 2 || batch < 1) return FNFT_EC_INVALID_ARGUMENT;
+    const int akns = nft_nse_to_akns((int)discretization);
+    if (akns < 0) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    if (!ensure_device(device)) return FNFT_EC_OTHER;
+    fnft_amd_plan *P = new (std::nothrow) fnft_amd_plan();
+    if (!P) return FNFT_EC_NOMEM;
+    P->device = device;
+    P->nse_disc = (int)discretization;
+    P->pl = new (std::nothrow) Plan(P->be, D, M, batch, akns, nft_akns_degree(akns));
+    if (!P->pl) { delete P; return FNFT_EC_NOMEM; }
+    const int rc = P->pl->init();
+    if (rc != NFT_SUCCESS || P->be.failed) {
+        P->pl->destroy();
+        delete P->pl;
+        delete P;
+        return rc != NFT_SUCCESS ? rc : FNFT_EC_NOMEM;
+    }
+    (void)P->be.sync();
+    *plan = P;
+    return FNFT_SUCCESS;
+}
+
+void fnft_amd_plan_destroy(fnft_amd_plan_t *plan)
+{
+    if (!plan) return;
+    (void)hipSetDevice(plan->device);
+    (void)hipDeviceSynchronize();
+    plan->pl->destroy();
+    plan->be.destroy_events();
+    delete plan->pl;
+    delete plan;
+}
+
+FNFT_UINT fnft_amd_plan_workspace_bytes(const fnft_amd_plan_t *plan) { return plan ? plan->pl->bytes : 0; }
+
+void fnft_amd_plan_set_timing(fnft_amd_plan_t *plan, int enabled)
+{
+    if (plan) plan->be.timing = enabled != 0;
+}
+
+double fnft_amd_plan_last_ms(const fnft_amd_plan_t *plan, int which)
+{
+    if (!plan) return -1.0;
+    switch (which) {
+    case 0: return plan->be.elapsed_ms(0, 1);
+    case 1: return plan->be.elapsed_ms(1, 2);
+    case 2: return plan->be.elapsed_ms(0, 2);
+    default: return -1.0;
+    }
+}
+
+FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, void *d_contspec,
+                                       const FNFT_REAL *T, const FNFT_REAL *XI, FNFT_INT kappa,
+                                       fnft_nsev_cstype_t contspec_type,
+                                       FNFT_INT normalization_flag, void *stream)
+{
+    if (!plan || !d_q || !T || !(T[0] < T[1])) return FNFT_EC_INVALID_ARGUMENT;
+    if (d_contspec && (!XI || !(XI[0] < XI[1]))) return FNFT_EC_INVALID_ARGUMENT;
+    if (kappa != 1 && kappa != -1) return FNFT_EC_INVALID_ARGUMENT;
+    const int cst = (int)contspec_type;
+    if (cst < 0 || cst > 2) return FNFT_EC_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(plan->mtx);
+    if (!hip_ok(hipSetDevice(plan->device), "hipSetDevice")) return FNFT_EC_OTHER;
+    Plan &pl = *plan->pl;
+    plan->be.stream = (hipStream_t)stream;
+    plan->be.failed = false;
+    const double eps_t = (T[1] - T[0]) / (double)(pl.D - 1);
+    plan->be.mark(0);
+    int rc = pl.run_coeffs(d_q, nullptr, eps_t, kappa);
+    if (rc == NFT_SUCCESS) rc = pl.run_tree();
+    plan->be.mark(1);
+    if (rc == NFT_SUCCESS && d_contspec && pl.M > 0) {
+        Plan::Contspec cs;
+        cs.T[0] = T[0]; cs.T[1] = T[1]; cs.XI[0] = XI[0]; cs.XI[1] = XI[1];
+        cs.nse_disc = plan->nse_disc;
+        cs.cstype = cst;
+        cs.normalization_flag = normalization_flag;
+        rc = pl.run_contspec(d_contspec, cs);
+    }
+    plan->be.mark(2);
+    if (plan->be.failed) return FNFT_EC_OTHER;
+    return rc;
+}
+
+FNFT_INT fnft_amd_plan_finish(fnft_amd_plan_t *plan, void *stream)
+{
+    if (!plan) return FNFT_EC_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(plan->mtx);
+    (void)hipSetDevice(plan->device);
+    plan->be.stream = (hipStream_t)stream;
+    return plan->pl->read_status();
+}
+
+FNFT_INT fnft_amd_plan_get_transfer_matrix(fnft_amd_plan_t *plan, FNFT_UINT b,
+                                           FNFT_COMPLEX *result_host, FNFT_UINT *deg, FNFT_INT *W)
+{
+    if (!plan || !result_host || !plan->pl->tree_valid || b >= plan->pl->batch)
+        return FNFT_EC_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(plan->mtx);
+    (void)hipSetDevice(plan->device);
+    Plan &pl = *plan->pl;
+    pl.export_tm();
+    const size_t per = 4 * (pl.res_deg + 1);
+    plan->be.d2h(result_host, pl.tm_out + b * per, per * sizeof(cplx));
+    int w = 0;
+    plan->be.d2h(&w, pl.W + b, sizeof(int));
+    const int rc = plan->be.sync();
+    if (deg) *deg = pl.res_deg;
+    if (W) *W = w;
+    return rc;
+}
+
+// ---- section 2: private-layer seam, host buffers ----------------------------------------------
+
+FNFT_UINT fnft__poly_fmult2x2_numel(const FNFT_UINT deg, const FNFT_UINT n)
+{
+    return 4 * (deg + 1) * (n == 0 ? 0 : nft_nextpow2(n));
+}
+
+FNFT_INT fnft__poly_fmult2x2(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *const p,
+                             FNFT_COMPLEX *const result, FNFT_INT *const W_ptr)
+{
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    HipBackend be;
+    return api_poly_fmult2x2(be, d, n, p, result, W_ptr);
+}
+
+FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const double *A,
+                              const double *W, const FNFT_UINT M, FNFT_COMPLEX *const result)
+{
+    if (!p || M == 0 || !result || !A || !W) return FNFT_EC_INVALID_ARGUMENT;
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    HipBackend be;
+    return Plan::chirpz_host(be, deg, p, {A[0], A[1]}, {W[0], W[1]}, M, result);
+}
+
+FNFT_INT fnft__poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const FNFT_COMPLEX A,
+                           const FNFT_COMPLEX W, const FNFT_UINT M, FNFT_COMPLEX *const result)
+{
+    const double a[2] = {A.real(), A.imag()}, w[2] = {W.real(), W.imag()};
+    return fnft_amd_poly_chirpz(deg, p, a, w, M, result);
+}
+
+FNFT_UINT fnft__akns_fscatter_numel(FNFT_UINT D, fnft__akns_discretization_t discretization)
+{
+    const int deg = nft_akns_degree((int)discretization);
+    return deg == 0 ? 0 : fnft__poly_fmult2x2_numel((FNFT_UINT)deg, D);
+}
+
+FNFT_INT fnft__akns_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q,
+                             FNFT_COMPLEX const *const r, const FNFT_REAL eps_t,
+                             FNFT_COMPLEX *const result, FNFT_UINT *const deg_ptr,
+                             FNFT_INT *const W_ptr, fnft__akns_discretization_t discretization)
+{
+    // argument checks in the reference's order, src/private/fnft__akns_fscatter.c:80-97
+    if (D == 0 || !q || !r || !(eps_t > 0.0) || !result || !deg_ptr) return FNFT_EC_INVALID_ARGUMENT;
+    if (nft_akns_degree((int)discretization) == 0) return FNFT_EC_INVALID_ARGUMENT;
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    HipBackend be;
+    return api_akns_fscatter(be, D, q, r, eps_t, 1, result, deg_ptr, W_ptr, (int)discretization);
+}
+
+FNFT_UINT fnft__nse_fscatter_numel(FNFT_UINT D, fnft_nse_discretization_t discretization)
+{
+    const int a = nft_nse_to_akns((int)discretization);
+    return a < 0 ? 0 : fnft__akns_fscatter_numel(D, (fnft__akns_discretization_t)a);
+}
+
+FNFT_INT fnft__nse_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q, const FNFT_REAL eps_t,
+                            const FNFT_INT kappa, FNFT_COMPLEX *const result,
+                            FNFT_UINT *const deg_ptr, FNFT_INT *const W_ptr,
+                            fnft_nse_discretization_t discretization)
+{
+    // src/private/fnft__nse_fscatter.c:55-69
+    if (D == 0 || !q || !(eps_t > 0.0) || (kappa != 1 && kappa != -1) || !result || !deg_ptr)
+        return FNFT_EC_INVALID_ARGUMENT;
+    const int a = nft_nse_to_akns((int)discretization);
+    if (a < 0) return FNFT_EC_INVALID_ARGUMENT;
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    HipBackend be;
+    return api_akns_fscatter(be, D, q, nullptr, eps_t, kappa, result, deg_ptr, W_ptr, a);
+}
+
+// ---- internal entry used by the C driver (fnft_nsev_host.c) ------------------------------------
+// Host buffers in, host buffers out; plans are cached per (D, M, discretization).
+FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const FNFT_REAL *T,
+                                      FNFT_UINT M, FNFT_COMPLEX *contspec, const FNFT_REAL *XI,
+                                      FNFT_INT kappa, int discretization, int contspec_type,
+                                      FNFT_INT normalization_flag)
+{
+    static std::mutex cache_mtx;
+    static std::map<std::tuple<size_t, size_t, int>, fnft_amd_plan *> cache;
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    fnft_amd_plan *P = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(cache_mtx);
+        auto key = std::make_tuple((size_t)D, (size_t)M, discretization);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            if (cache.size() >= 4) {  // keep the workspace footprint bounded
+                for (auto &kv : cache) fnft_amd_plan_destroy(kv.second);
+                cache.clear();
+            }
+            const FNFT_INT rc = fnft_amd_plan_create(&P, D, M, 1,
+                                                     (fnft_nse_discretization_t)discretization, 0);
+            if (rc != FNFT_SUCCESS) return rc;
+            cache[key] = P;
+        } else {
+            P = it->second;
+        }
+    }
+    const size_t cs_len = M * (contspec_type == 0 ? 1 : (contspec_type == 1 ? 2 : 3));
+    cplx *dq = nullptr, *dcs = nullptr;
+    if (!hip_ok(hipMalloc((void **)&dq, D * sizeof(cplx)), "hipMalloc")) return FNFT_EC_NOMEM;
+    if (!hip_ok(hipMalloc((void **)&dcs, (cs_len ? cs_len : 1) * sizeof(cplx)), "hipMalloc")) {
+        (void)hipFree(dq);
+        return FNFT_EC_NOMEM;
+    }
+    FNFT_INT rc = FNFT_SUCCESS;
+    if (!hip_ok(hipMemcpy(dq, q, D * sizeof(cplx), hipMemcpyHostToDevice), "hipMemcpy(H2D)"))
+        rc = FNFT_EC_OTHER;
+    if (rc == FNFT_SUCCESS)
+        rc = fnft_amd_nsev_contspec_device(P, dq, contspec ? dcs : nullptr, T, XI, kappa,
+                                           (fnft_nsev_cstype_t)contspec_type, normalization_flag,
+                                           nullptr);
+    if (rc == FNFT_SUCCESS) rc = fnft_amd_plan_finish(P, nullptr);
+    if (rc == FNFT_SUCCESS && contspec && cs_len)
+        if (!hip_ok(hipMemcpy(contspec, dcs, cs_len * sizeof(cplx), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+            rc = FNFT_EC_OTHER;
+    (void)hipFree(dq);
+    (void)hipFree(dcs);
+    return rc;
+}
+
+}  // extern "C"

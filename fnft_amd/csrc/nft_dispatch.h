@@ -1,0 +1,205 @@
+// nft_dispatch.h -- kernel functors (one per kernel body + tiling) and the run-time -> compile-time
+// dispatch shared by the HIP back end (hip_backend.hip) and the CPU lane emulator (tests/emu).
+//
+// A kernel functor K provides: Params, THREADS, lds_bytes(), body(const Params&).
+// A back end BE provides: template<class K> void run(int gx, int gy, const typename K::Params&).
+#pragma once
+#include "nft_kernels.h"
+
+constexpr int kRowLen = 4096;       // N2 of every split transform
+constexpr int kFusedMaxN = 4096;    // largest pair product done by one workgroup
+constexpr int kSchoolMaxDeg = 3;    // direct products up to this input degree
+
+// ---- simple one-lane-per-item kernels --------------------------------------------------------
+template <int DEG> struct KCoeffs {
+    using Params = CoeffParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_coeffs<DEG>(p); }
+};
+template <int DEG> struct KPairSchool {
+    using Params = TreeLevel;
+    static constexpr int THREADS = 128;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_pair_school<DEG>(p); }
+};
+struct KFinalizeScales {
+    using Params = TreeLevel;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_finalize_scales(p); }
+};
+struct KExportTm {
+    using Params = ExportParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_export_tm(p); }
+};
+
+// ---- fused pair product ----------------------------------------------------------------------
+template <int N> struct PairCfg {
+    static constexpr int R = 8;
+    static constexpr int THREADS = (N / R > 256) ? N / R : 256;
+    static constexpr int B = THREADS / (N / R);
+};
+template <int N> struct KPairFft {
+    using Params = TreeLevel;
+    using C = PairCfg<N>;
+    static constexpr int THREADS = C::THREADS;
+    // 1 wave/SIMD for 256-lane groups (no scratch spills at ~400 registers); the 512-lane
+    // N = 4096 group needs 2 waves/SIMD to be resident at all
+    static constexpr int MIN_WAVES = (C::THREADS > 256) ? 2 : 1;
+    static constexpr size_t lds_bytes()
+    {
+        return (N > C::R ? (size_t)2 * N * C::B * sizeof(cplx) : 0) + (size_t)C::B * 8;
+    }
+    static FA_DEV void body(const Params &p) { body_pair_fft<N, C::R, C::B>(p); }
+};
+
+// ---- split transforms ------------------------------------------------------------------------
+template <int N1> struct ColCfg {
+    static constexpr int R = (N1 <= 16) ? N1 : (N1 <= 256 ? 8 : 16);
+    static constexpr int THREADS = (N1 <= 256) ? 256 : 512;
+    static constexpr int BC = THREADS / (N1 / R);
+    static constexpr bool DB = (N1 <= 256);
+    static constexpr size_t lds_bytes()
+    {
+        return (N1 > R) ? (size_t)(DB ? 2 : 1) * N1 * BC * sizeof(cplx) : 0;
+    }
+};
+template <int N1> struct KColFwd {
+    using Params = BigLevel;
+    using C = ColCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_col_fwd<N1, C::R, C::BC, C::DB>(p); }
+};
+template <int N1> struct KColInv {
+    using Params = BigLevel;
+    using C = ColCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_col_inv<N1, C::R, C::BC, C::DB>(p); }
+};
+struct KMid {
+    using Params = BigLevel;
+    static constexpr int R = 8;
+    static constexpr int THREADS = kRowLen / R;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes() { return (size_t)2 * kRowLen * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_mid<kRowLen, R>(p); }
+};
+template <int N1> struct KChirpColFwd {
+    using Params = ChirpParams;
+    using C = ColCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_chirp_col_fwd<N1, C::R, C::BC, C::DB>(p); }
+};
+template <int N1> struct KChirpColInv {
+    using Params = ChirpParams;
+    using C = ColCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_chirp_col_inv<N1, C::R, C::BC, C::DB>(p); }
+};
+struct KChirpRows {
+    using Params = ChirpParams;
+    static constexpr int R = 8;
+    static constexpr int THREADS = kRowLen / R;
+    static constexpr size_t lds_bytes() { return (size_t)2 * kRowLen * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_chirp_rows<kRowLen, R, true>(p); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// dispatch: returns false if the size is not instantiated
+// ---------------------------------------------------------------------------------------------
+template <class BE> bool dispatch_coeffs(BE &be, const CoeffParams &p)
+{
+    const long long n = (long long)p.batch * p.Dpad;
+    const int g = (int)((n + 255) / 256);
+    switch (p.deg) {
+    case 1: be.template run<KCoeffs<1>>(g, 1, p); return true;
+    case 2: be.template run<KCoeffs<2>>(g, 1, p); return true;
+    case 3: be.template run<KCoeffs<3>>(g, 1, p); return true;
+    case 4: be.template run<KCoeffs<4>>(g, 1, p); return true;
+    default: return false;
+    }
+}
+
+template <class BE> bool dispatch_pair_school(BE &be, const TreeLevel &L)
+{
+    const int pairs = L.n_in / 2;
+    const int g = (pairs + 127) / 128;
+    switch (L.d) {
+    case 1: be.template run<KPairSchool<1>>(g, 1, L); return true;
+    case 2: be.template run<KPairSchool<2>>(g, 1, L); return true;
+    case 3: be.template run<KPairSchool<3>>(g, 1, L); return true;
+    default: return false;
+    }
+}
+
+template <class BE, int N> void run_pair_fft(BE &be, const TreeLevel &L)
+{
+    const int pairs = L.n_in / 2;
+    constexpr int B = PairCfg<N>::B;
+    be.template run<KPairFft<N>>((pairs + B - 1) / B, 1, L);
+}
+template <class BE> bool dispatch_pair_fft(BE &be, const TreeLevel &L, int N)
+{
+    switch (N) {
+    case 8: run_pair_fft<BE, 8>(be, L); return true;
+    case 16: run_pair_fft<BE, 16>(be, L); return true;
+    case 32: run_pair_fft<BE, 32>(be, L); return true;
+    case 64: run_pair_fft<BE, 64>(be, L); return true;
+    case 128: run_pair_fft<BE, 128>(be, L); return true;
+    case 256: run_pair_fft<BE, 256>(be, L); return true;
+    case 512: run_pair_fft<BE, 512>(be, L); return true;
+    case 1024: run_pair_fft<BE, 1024>(be, L); return true;
+    case 2048: run_pair_fft<BE, 2048>(be, L); return true;
+    case 4096: run_pair_fft<BE, 4096>(be, L); return true;
+    default: return false;
+    }
+}
+
+#define FA_FOR_EACH_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+
+template <class BE> bool dispatch_col_fwd(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * G.L.n_in;
+    switch (G.N1) {
+#define X(n1) case n1: be.template run<KColFwd<n1>>(kRowLen / ColCfg<n1>::BC, polys, G); return true;
+        FA_FOR_EACH_N1(X)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_col_inv(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * (G.L.n_in / 2);
+    switch (G.N1) {
+#define X(n1) case n1: be.template run<KColInv<n1>>(kRowLen / ColCfg<n1>::BC, polys, G); return true;
+        FA_FOR_EACH_N1(X)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_chirp_col_fwd(BE &be, const ChirpParams &C)
+{
+    const int jobs = C.batch * C.npoly + 1;
+    switch (C.N1) {
+#define X(n1) case n1: be.template run<KChirpColFwd<n1>>(kRowLen / ColCfg<n1>::BC, jobs, C); return true;
+        FA_FOR_EACH_N1(X)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_chirp_col_inv(BE &be, const ChirpParams &C)
+{
+    switch (C.N1) {
+#define X(n1) case n1: be.template run<KChirpColInv<n1>>(kRowLen / ColCfg<n1>::BC, C.batch, C); return true;
+        FA_FOR_EACH_N1(X)
+#undef X
+    default: return false;
+    }
+}

@@ -1,0 +1,869 @@
+// nft_kernels.h -- kernel bodies of the MI355X fnft_nsev hot path.
+//
+// Reference functions replaced (file:line relative to the FNFT source tree):
+//   body_coeffs            src/private/fnft__akns_fscatter.c:116-917 (per-sample 2x2 coefficients),
+//                          src/private/fnft__nse_fscatter.c:71-84 (r = -kappa*conj(q))
+//   body_pair_school       src/private/fnft__poly_fmult.c:239-328 for tiny degrees (direct products)
+//   body_pair_fft          src/private/fnft__poly_fmult.c:239-328,330-374 (one pair product + rescale)
+//   body_col_fwd/mid/inv   the same pair product when one transform no longer fits a workgroup
+//   body_finalize_scales   src/private/fnft__poly_fmult.c:330-374 (rescale bookkeeping)
+//   body_export_tm         src/private/fnft__poly_fmult.c:522-538 (final layout)
+//   body_chirp_*           src/private/fnft__poly_chirpz.c:52-95, src/fnft_nsev.c:837-884
+//
+// HBM layout ("body/tail"): a level holds n matrices of degree d.  Entry e (11,12,21,22) is a
+// plane of `plane` complex128; matrix j's coefficients of powers d..1 (highest first, as in the
+// reference) are body[e*plane + j*d + k], k < d, and its constant term is tail[e*n + j].  Keeping
+// the odd "+1" coefficient out of the body makes every body a power-of-two run of 16-byte
+// elements and lets a product of two degree-d matrices use a cyclic transform of length 2d: the
+// only aliased coefficient, index 2d, is the product of the two constant terms and is formed
+// directly.  scale[j] is a pending power of two (true matrix = stored * scale[j]); W[signal]
+// accumulates the exponents taken out, true product = stored * 2^W (fnft__poly_fmult.c:493).
+#pragma once
+#include "fft_dev.h"
+
+// ---------------------------------------------------------------------------------------------
+// parameter blocks
+// ---------------------------------------------------------------------------------------------
+struct TreeLevel {
+    const cplx *body_in;
+    const cplx *tail_in;
+    const double *scale_in;
+    cplx *body_out;
+    cplx *tail_out;
+    double *scale_out;
+    unsigned long long *max2_out;  // per output matrix: bits of max |coef|^2 (large path)
+    int *W;                        // per signal
+    size_t plane;                  // body plane stride, elements
+    int n_in;                      // matrices entering this level (all signals)
+    int d;                         // their degree
+    int pairs_per_signal;          // (n_in/2)/batch
+    const cplx *tw;                // exp(-2 pi i j/N) table of the transform length used
+};
+
+// floor(log2(sqrt(m2))) for m2 > 0 (normal), exactly, from the exponent field
+FA_HD int half_exponent(double m2)
+{
+    union { double d; unsigned long long u; } cv;
+    cv.d = m2;
+    const int e = (int)((cv.u >> 52) & 0x7ffull) - 1023;
+    return e >> 1;  // arithmetic shift = floor(e/2)
+}
+FA_HD double pow2i(int a)
+{
+    union { double d; unsigned long long u; } cv;
+    cv.u = (unsigned long long)(a + 1023) << 52;
+    return cv.d;
+}
+FA_HD unsigned long long dbits(double x)
+{
+    union { double d; unsigned long long u; } cv;
+    cv.d = x;
+    return cv.u;
+}
+FA_HD double bitsd(unsigned long long u)
+{
+    union { double d; unsigned long long u; } cv;
+    cv.u = u;
+    return cv.d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// complex elementary functions needed by the coefficient kernel
+// (libm csqrt/ccos/csin of src/private/fnft__akns_fscatter.c:46-59, fnft__misc.c:306-314)
+// ---------------------------------------------------------------------------------------------
+FA_DEV cplx c_sqrt(cplx z)
+{
+    if (z.x == 0.0 && z.y == 0.0) return cmake(0.0, z.y);
+    const double ax = fabs(z.x), ay = fabs(z.y);
+    const double hm = sqrt(fma(ax, ax, ay * ay));
+    const double t = sqrt(0.5 * (ax + hm));
+    if (z.x >= 0.0) return cmake(t, z.y / (2.0 * t));
+    return cmake(ay / (2.0 * t), z.y < 0.0 ? -t : t);
+}
+FA_DEV cplx c_cos(cplx z)
+{
+    double s, c;
+    fa_sincos(z.x, &s, &c);
+    return cmake(c * cosh(z.y), -s * sinh(z.y));
+}
+FA_DEV cplx c_sin(cplx z)
+{
+    double s, c;
+    fa_sincos(z.x, &s, &c);
+    return cmake(s * cosh(z.y), c * sinh(z.y));
+}
+FA_DEV cplx c_div(cplx a, cplx b)
+{
+    // Smith's algorithm
+    if (fabs(b.x) >= fabs(b.y)) {
+        const double r = b.y / b.x, den = b.x + b.y * r;
+        return cmake((a.x + a.y * r) / den, (a.y - a.x * r) / den);
+    }
+    const double r = b.x / b.y, den = b.x * r + b.y;
+    return cmake((a.x * r + a.y) / den, (a.y * r - a.x) / den);
+}
+FA_DEV cplx c_sinc(cplx z)
+{
+    if (sqrt(cnorm2(z)) >= 1.0e-8) return c_div(c_sin(z), z);
+    return c_cos(z * 0.57735026918962576451);  // cos(z/sqrt(3)), fnft__misc.c:313
+}
+
+// expm([[0,q],[r,0]]*h) = [[c, q*s],[r*s, c]]  (fnft__akns_fscatter.c:46-59)
+struct StepExp {
+    cplx c, qs, rs;
+};
+FA_DEV StepExp zero_freq_step(double h, cplx q, cplx r)
+{
+    StepExp e;
+    const cplx mqr = cmake(-(q.x * r.x - q.y * r.y), -(q.x * r.y + q.y * r.x));
+    const cplx Delta = c_sqrt(mqr) * h;
+    const cplx del = c_sinc(Delta) * h;
+    e.c = c_cos(Delta);
+    e.qs = q * del;
+    e.rs = r * del;
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: per-sample coefficients
+// ---------------------------------------------------------------------------------------------
+struct CoeffParams {
+    const cplx *q;       // batch*D
+    const cplx *r;       // batch*D or NULL (then r = -kappa*conj(q))
+    cplx *body;          // 4 planes
+    cplx *tail;          // 4 planes of n = batch*Dpad
+    double *scale;       // n
+    int *status;         // bit 0: MODAL step-size check failed
+    size_t plane;
+    double eps_t;
+    int D, Dpad, batch, kappa;
+    int disc;            // fnft__akns_discretization_t ordinal
+    int deg;
+};
+
+// coefficient tables: P[e][k], k <= deg, highest power first
+template <int DEG> struct CoefMat {
+    cplx p[4][DEG + 1];
+};
+
+template <int DEG> FA_DEV void coeffs_zero(CoefMat<DEG> &m)
+{
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int k = 0; k <= DEG; k++) m.p[e][k] = cmake(0.0, 0.0);
+}
+
+// Returns false when the MODAL step-size condition is violated (fnft__akns_fscatter.c:122-126).
+template <int DEG> FA_DEV bool sample_coeffs(int disc, double eps_t, cplx q, cplx r, CoefMat<DEG> &m)
+{
+    coeffs_zero(m);
+    const double h = eps_t / (double)DEG;
+    if constexpr (DEG == 1) {
+        if (disc == 0) {  // 2SPLIT2_MODAL, :118-148
+            bool ok = true;
+            if (q.x == r.x && eps_t * sqrt(cnorm2(q)) >= 1.0) ok = false;
+            const cplx eq = q * eps_t, er = r * eps_t;
+            const cplx one_m = cmake(1.0 - (eq.x * er.x - eq.y * er.y), -(eq.x * er.y + eq.y * er.x));
+            const cplx s = c_div(cmake(1.0, 0.0), c_sqrt(one_m));
+            m.p[0][1] = s;
+            m.p[1][0] = s * eq;
+            m.p[2][1] = s * er;
+            m.p[3][0] = s;
+            return ok;
+        }
+        if (disc == 1) {  // 2SPLIT1A, :150-176
+            const StepExp e = zero_freq_step(h, q, r);
+            m.p[0][1] = e.c; m.p[1][1] = e.qs; m.p[2][0] = e.rs; m.p[3][0] = e.c;
+            return true;
+        }
+        if (disc == 2 || disc == 3) {  // 2SPLIT1B / 2SPLIT2A, :178-203
+            const StepExp e = zero_freq_step(h, q, r);
+            m.p[0][1] = e.c; m.p[1][0] = e.qs; m.p[2][1] = e.rs; m.p[3][0] = e.c;
+            return true;
+        }
+        if (disc == 4) {  // 2SPLIT2B, :204-228
+            const StepExp e = zero_freq_step(0.5 * h, q, r);
+            m.p[0][0] = e.qs * e.rs; m.p[0][1] = e.c * e.c;
+            m.p[1][0] = m.p[1][1] = e.c * e.qs;
+            m.p[2][0] = m.p[2][1] = e.c * e.rs;
+            m.p[3][0] = m.p[0][1]; m.p[3][1] = m.p[0][0];
+            return true;
+        }
+        // 2SPLIT2S, :230-254
+        const StepExp e = zero_freq_step(h, q, r);
+        m.p[0][1] = e.c;
+        m.p[1][0] = m.p[1][1] = e.qs * 0.5;
+        m.p[2][0] = m.p[2][1] = e.rs * 0.5;
+        m.p[3][0] = e.c;
+        return true;
+    } else if constexpr (DEG == 2) {
+        if (disc == 8) {  // 2SPLIT3S, :331-361
+            const StepExp e1 = zero_freq_step(h, q, r), e2 = zero_freq_step(2 * h, q, r);
+            m.p[0][0] = (e1.qs * e1.rs) * (2.0 / 3.0);
+            m.p[0][2] = ((e1.c * e1.c) * 2.0 + e2.c) * (1.0 / 3.0);
+            m.p[1][0] = m.p[1][2] = ((e1.c * e1.qs) * 4.0 - e2.qs) * (1.0 / 6.0);
+            m.p[1][1] = e2.qs * (2.0 / 3.0);
+            m.p[2][0] = m.p[2][2] = ((e1.c * e1.rs) * 4.0 - e2.rs) * (1.0 / 6.0);
+            m.p[2][1] = e2.rs * (2.0 / 3.0);
+            m.p[3][0] = m.p[0][2]; m.p[3][2] = m.p[0][0];
+            return true;
+        }
+        // 2SPLIT4B (and 4SPLIT4B), :402-433
+        const StepExp eh = zero_freq_step(0.5 * h, q, r), e1 = zero_freq_step(h, q, r);
+        const double t3 = 1.0 / 3.0;
+        m.p[0][0] = ((e1.c * eh.qs * eh.rs) * 4.0 - e1.qs * e1.rs) * t3;
+        m.p[0][1] = (e1.qs * eh.c * eh.rs + e1.rs * eh.c * eh.qs) * (4.0 * t3);
+        m.p[0][2] = ((e1.c * eh.c * eh.c) * 4.0 - e1.c * e1.c) * t3;
+        m.p[1][0] = m.p[1][2] = ((e1.c * eh.c * eh.qs) * 4.0 - e1.c * e1.qs) * t3;
+        m.p[1][1] = (e1.qs * eh.c * eh.c + e1.rs * eh.qs * eh.qs) * (4.0 * t3);
+        m.p[2][0] = m.p[2][2] = ((e1.c * eh.c * eh.rs) * 4.0 - e1.c * e1.rs) * t3;
+        m.p[2][1] = (e1.rs * eh.c * eh.c + e1.qs * eh.rs * eh.rs) * (4.0 * t3);
+        m.p[3][0] = m.p[0][2]; m.p[3][1] = m.p[0][1]; m.p[3][2] = m.p[0][0];
+        return true;
+    } else if constexpr (DEG == 3) {
+        const StepExp e1 = zero_freq_step(h, q, r), e2 = zero_freq_step(2 * h, q, r),
+                      e3 = zero_freq_step(3 * h, q, r);
+        const double n8 = 9.0 / 8.0, i8 = 1.0 / 8.0;
+        if (disc == 6) {  // 2SPLIT3A, :256-292
+            m.p[0][1] = (e1.rs * e2.qs) * n8; m.p[0][3] = ((e1.c * e2.c) * 9.0 - e3.c) * i8;
+            m.p[1][1] = (e1.c * e2.qs) * n8;  m.p[1][3] = ((e1.qs * e2.c) * 9.0 - e3.qs) * i8;
+            m.p[2][0] = ((e1.rs * e2.c) * 9.0 - e3.rs) * i8; m.p[2][2] = (e1.c * e2.rs) * n8;
+            m.p[3][0] = m.p[0][3]; m.p[3][2] = (e1.qs * e2.rs) * n8;
+        } else {  // 2SPLIT3B, :294-330
+            m.p[0][1] = (e1.qs * e2.rs) * n8; m.p[0][3] = ((e1.c * e2.c) * 9.0 - e3.c) * i8;
+            m.p[1][0] = ((e1.qs * e2.c) * 9.0 - e3.qs) * i8; m.p[1][2] = (e1.c * e2.qs) * n8;
+            m.p[2][1] = (e1.c * e2.rs) * n8; m.p[2][3] = ((e1.rs * e2.c) * 9.0 - e3.rs) * i8;
+            m.p[3][0] = m.p[0][3]; m.p[3][2] = (e1.rs * e2.qs) * n8;
+        }
+        return true;
+    } else {  // DEG == 4: 2SPLIT4A (and 4SPLIT4A), :362-401
+        const StepExp e2 = zero_freq_step(2 * h, q, r), e4 = zero_freq_step(4 * h, q, r);
+        const double t3 = 1.0 / 3.0;
+        m.p[0][2] = (e2.qs * e2.rs) * (4.0 * t3);
+        m.p[0][4] = ((e2.c * e2.c) * 4.0 - e4.c) * t3;
+        m.p[1][1] = m.p[1][3] = (e2.c * e2.qs) * (4.0 * t3);
+        m.p[1][2] = e4.qs * (-t3);
+        m.p[2][1] = m.p[2][3] = (e2.c * e2.rs) * (4.0 * t3);
+        m.p[2][2] = e4.rs * (-t3);
+        m.p[3][0] = m.p[0][4]; m.p[3][2] = m.p[0][2];
+        return true;
+    }
+}
+
+// one lane per matrix slot j of the padded level 0; slot j of signal b holds sample D-1-j
+// (fnft__akns_fscatter.c:120) or the identity pad z^deg*I (fnft__poly_fmult.c:422-438).
+template <int DEG> FA_DEV void body_coeffs(const CoeffParams &P)
+{
+    const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long n = (long long)P.batch * P.Dpad;
+    if (gid >= n) return;
+    const int b = (int)(gid / P.Dpad), j = (int)(gid % P.Dpad);
+    CoefMat<DEG> m;
+    if (j < P.D) {
+        const size_t src = (size_t)b * P.D + (size_t)(P.D - 1 - j);
+        const cplx q = P.q[src];
+        const cplx r = P.r ? P.r[src] : (P.kappa == 1 ? cmake(-q.x, q.y) : cmake(q.x, -q.y));
+        if (!sample_coeffs<DEG>(P.disc, P.eps_t, q, r, m)) fa_atomic_or_i32(P.status, 1);
+    } else {
+        coeffs_zero(m);
+        m.p[0][0] = cmake(1.0, 0.0);
+        m.p[3][0] = cmake(1.0, 0.0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) P.body[(size_t)e * P.plane + (size_t)gid * DEG + k] = m.p[e][k];
+        P.tail[(size_t)e * n + gid] = m.p[e][DEG];
+    }
+    P.scale[gid] = 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a: direct ("schoolbook") pair product, one lane per pair, for degrees too small for an FFT
+// ---------------------------------------------------------------------------------------------
+template <int DEG> FA_DEV void body_pair_school(const TreeLevel &L)
+{
+    const long long P = (long long)FA_BID * FA_BDIM + FA_TID;
+    const int n_out = L.n_in / 2;
+    if (P >= n_out) return;
+    constexpr int d = DEG;
+    cplx A[4][d + 1], Bm[4][d + 1];
+    const double sA = L.scale_in[2 * P], sB = L.scale_in[2 * P + 1];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int k = 0; k < d; k++) {
+            A[e][k] = L.body_in[(size_t)e * L.plane + (size_t)(2 * P) * d + k] * sA;
+            Bm[e][k] = L.body_in[(size_t)e * L.plane + (size_t)(2 * P + 1) * d + k] * sB;
+        }
+        A[e][d] = L.tail_in[(size_t)e * L.n_in + 2 * P] * sA;
+        Bm[e][d] = L.tail_in[(size_t)e * L.n_in + 2 * P + 1] * sB;
+    }
+    cplx C[4][2 * d + 1];
+    double m2 = 0.0;
+#pragma unroll
+    for (int row = 0; row < 2; row++)
+#pragma unroll
+        for (int col = 0; col < 2; col++) {
+            const int e = 2 * row + col;
+#pragma unroll
+            for (int k = 0; k <= 2 * d; k++) C[e][k] = cmake(0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i <= d; i++)
+#pragma unroll
+                for (int j = 0; j <= d; j++) {
+                    C[e][i + j] = cfma(A[2 * row][i], Bm[col][j], C[e][i + j]);
+                    C[e][i + j] = cfma(A[2 * row + 1][i], Bm[2 + col][j], C[e][i + j]);
+                }
+#pragma unroll
+            for (int k = 0; k <= 2 * d; k++) m2 = fmax(m2, cnorm2(C[e][k]));
+        }
+    int a = 0;
+    double sc = 1.0;
+    if (m2 > 0.0 && m2 < 1.0e300) {
+        a = half_exponent(m2);
+        sc = pow2i(-a);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int k = 0; k < 2 * d; k++)
+            L.body_out[(size_t)e * L.plane + (size_t)P * (2 * d) + k] = C[e][k] * sc;
+        L.tail_out[(size_t)e * n_out + P] = C[e][2 * d] * sc;
+    }
+    L.scale_out[P] = 1.0;
+    if (a != 0) fa_atomic_add_i32(&L.W[P / L.pairs_per_signal], a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2b: FFT pair product, one group of N/R lanes per pair, B pairs per workgroup.
+// A's four spectra stay in registers; B is streamed one column at a time:
+//   C(:,col) = A * B(:,col)  ->  2 forward transforms, 8 complex multiply-adds per bin,
+//   2 inverse transforms, stored; total 8 forward + 4 inverse as in the reference.
+// IO supplies the loads/stores so that the same body serves a whole tree level (TreeIO) and the
+// row step of a transform that is split across workgroups (MidIO).
+// ---------------------------------------------------------------------------------------------
+template <int N, int R, int B, class IO> FA_DEV void pair_product_core(IO &io, cplx *lds, const cplx *tw)
+{
+    const int tid = FA_TID;
+    const int c = tid % B, v = tid / B;
+    int parity = 0;
+    cplx a[4][R];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        io.load(0, e, a[e], v, c);
+        fft_wg<N, R, B, -1>(a[e], lds, v, c, tw, parity);
+    }
+#pragma unroll
+    for (int col = 0; col < 2; col++) {
+        cplx b1[R], b2[R];
+        io.load(1, col, b1, v, c);
+        fft_wg<N, R, B, -1>(b1, lds, v, c, tw, parity);
+        io.load(1, 2 + col, b2, v, c);
+        fft_wg<N, R, B, -1>(b2, lds, v, c, tw, parity);
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const cplx x1 = b1[i], x2 = b2[i];
+            b1[i] = cfma(a[1][i], x2, a[0][i] * x1);
+            b2[i] = cfma(a[3][i], x2, a[2][i] * x1);
+        }
+        fft_wg<N, R, B, +1>(b1, lds, v, c, tw, parity);
+        io.store(col, b1, v, c);
+        fft_wg<N, R, B, +1>(b2, lds, v, c, tw, parity);
+        io.store(2 + col, b2, v, c);
+    }
+}
+
+template <int N, int R, int B> struct TreeIO {
+    const TreeLevel &L;
+    long long P;      // pair handled by this lane's group
+    bool active;
+    double sc[2];
+    double m2;        // running max |coef|^2 of this lane's outputs
+
+    FA_DEV TreeIO(const TreeLevel &L_, int c) : L(L_)
+    {
+        P = (long long)FA_BID * B + c;
+        active = P < L.n_in / 2;
+        m2 = 0.0;
+        sc[0] = active ? L.scale_in[2 * P] : 0.0;
+        sc[1] = active ? L.scale_in[2 * P + 1] : 0.0;
+    }
+    FA_DEV cplx tail(int which, int e) const
+    {
+        return L.tail_in[(size_t)e * L.n_in + 2 * P + which] * sc[which];
+    }
+    // which: 0 = left factor (A), 1 = right factor (B)
+    FA_DEV void load(int which, int e, cplx (&x)[R], int v, int)
+    {
+        const int d = L.d;
+        const cplx *src = L.body_in + (size_t)e * L.plane + (size_t)(2 * P + which) * d;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int idx = v + (N / R) * i;
+            cplx val = cmake(0.0, 0.0);
+            if (active) {
+                if (idx < d) val = src[idx] * sc[which];
+                else if (idx == d) val = tail(which, e);
+            }
+            x[i] = val;
+        }
+    }
+    FA_DEV cplx tail_product(int e) const
+    {
+        const int row = e >> 1, col = e & 1;
+        return cfma(tail(0, 2 * row + 1), tail(1, 2 + col), tail(0, 2 * row) * tail(1, col));
+    }
+    FA_DEV void store(int e, cplx (&x)[R], int v, int)
+    {
+        if (!active) return;
+        const int d2 = 2 * L.d;
+        cplx *dst = L.body_out + (size_t)e * L.plane + (size_t)P * d2;
+        const double inv = 1.0 / (double)N;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int idx = v + (N / R) * i;
+            cplx val = x[i] * inv;
+            if (idx == 0) {
+                const cplx tp = tail_product(e);
+                if (N == d2) val = val - tp;  // un-alias coefficient 2d folded onto 0
+                L.tail_out[(size_t)e * (L.n_in / 2) + P] = tp;
+                m2 = fmax(m2, cnorm2(tp));
+            }
+            if (idx < d2) {
+                dst[idx] = val;
+                m2 = fmax(m2, cnorm2(val));
+            }
+        }
+    }
+};
+
+// LDS: 2*N*B transform buffers (none when N == R), then B u64 slots for the per-pair maxima.
+template <int N, int R, int B> FA_DEV void body_pair_fft(const TreeLevel &L)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    unsigned long long *mx = (unsigned long long *)(lds + (N > R ? (size_t)2 * N * B : 0));
+    const int tid = FA_TID;
+    const int c = tid % B, v = tid / B;
+    if (v == 0) mx[c] = 0ull;
+    TreeIO<N, R, B> io(L, c);
+    pair_product_core<N, R, B>(io, lds, L.tw);
+    // every lane's first fft_wg exchange has passed a barrier after mx was zeroed when N > R;
+    // for N == R (single pass, no barrier) the group is one lane, so order is trivial.
+    if (N > R) {
+        if (io.active) fa_atomic_max_u64(&mx[c], dbits(io.m2));
+        FA_SYNC();
+    } else {
+        mx[c] = dbits(io.m2);
+    }
+    if (v == 0 && io.active) {
+        const double m2 = bitsd(mx[c]);
+        int a = 0;
+        if (m2 > 0.0 && m2 < 1.0e300) a = half_exponent(m2);
+        L.scale_out[io.P] = pow2i(-a);
+        if (a != 0) fa_atomic_add_i32(&L.W[io.P / L.pairs_per_signal], a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large transforms: N = N1 * N2 with element index n = n1*N2 + n2 and bin k = k1 + N1*k2.
+//   forward : column DFT over n1 (size N1), twiddle w_N^{n2 k1}, row DFT over n2 (size N2)
+//   inverse : row IDFT over k2, twiddle conj, column IDFT over k1
+// Y/Z scratch layout: [poly][k1][n2], poly = e*n_mats + mat.
+// ---------------------------------------------------------------------------------------------
+struct BigLevel {
+    TreeLevel L;
+    cplx *Y;         // forward scratch: 4*n_in polys of N
+    cplx *Z;         // inverse scratch: 4*(n_in/2) polys of N
+    BigTwiddle btw;  // exp(-2 pi i j/N)
+    const cplx *tw1; // table for N1
+    const cplx *tw2; // table for N2
+    int N1, N2;
+};
+
+// column step of the forward transform of every input polynomial of the level
+//   grid.x = N2/BC tiles, grid.y = 4*n_in polynomials
+template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLevel &G)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int poly = FA_BID_Y;
+    const int e = poly / L.n_in, mat = poly % L.n_in;
+    const int d = L.d, N2 = G.N2;
+    const double sc = L.scale_in[mat];
+    const cplx *src = L.body_in + (size_t)e * L.plane + (size_t)mat * d;
+    cplx x[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n1 = v + (N1 / R) * i;
+        const long long idx = (long long)n1 * N2 + n2;
+        cplx val = cmake(0.0, 0.0);
+        if (idx < d) val = src[idx] * sc;
+        else if (idx == d) val = L.tail_in[(size_t)e * L.n_in + mat] * sc;
+        x[i] = val;
+    }
+    int parity = 0;
+    fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, G.tw1, parity);
+    cplx *dst = G.Y + (size_t)poly * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int k1 = v + (N1 / R) * i;
+        const cplx w = big_twiddle(G.btw, (unsigned)k1 * (unsigned)n2);
+        dst[(size_t)k1 * N2 + n2] = x[i] * w;
+    }
+}
+
+// row step: one workgroup per (pair, k1): 8 forward row transforms, products, 4 inverse
+template <int N2, int R> struct MidIO {
+    const BigLevel &G;
+    long long P;
+    int k1;
+    FA_DEV MidIO(const BigLevel &G_) : G(G_)
+    {
+        P = FA_BID / G.N1;
+        k1 = FA_BID % G.N1;
+    }
+    FA_DEV void load(int which, int e, cplx (&x)[R], int v, int)
+    {
+        const int n_in = G.L.n_in;
+        const cplx *src = G.Y + ((size_t)((size_t)e * n_in + 2 * P + which) * G.N1 + k1) * N2;
+#pragma unroll
+        for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i];
+    }
+    FA_DEV void store(int e, cplx (&x)[R], int v, int)
+    {
+        const int n_out = G.L.n_in / 2;
+        cplx *dst = G.Z + ((size_t)((size_t)e * n_out + P) * G.N1 + k1) * N2;
+        const double inv = 1.0 / (double)N2;
+#pragma unroll
+        for (int i = 0; i < R; i++) dst[v + (N2 / R) * i] = x[i] * inv;
+    }
+};
+
+template <int N2, int R> FA_DEV void body_mid(const BigLevel &G)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    MidIO<N2, R> io(G);
+    pair_product_core<N2, R, 1>(io, lds, G.tw2);
+}
+
+// column step of the inverse transform of every output polynomial
+//   grid.x = N2/BC tiles, grid.y = 4*n_out polynomials
+template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLevel &G)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int poly = FA_BID_Y;
+    const int n_out = L.n_in / 2;
+    const int e = poly / n_out, P = poly % n_out;
+    const int N2 = G.N2;
+    const long long N = (long long)N1 * N2;
+    const int d2 = 2 * L.d;
+    const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    cplx x[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int k1 = v + (N1 / R) * i;
+        const cplx w = cconj(big_twiddle(G.btw, (unsigned)k1 * (unsigned)n2));
+        x[i] = src[(size_t)k1 * N2 + n2] * w;
+    }
+    int parity = 0;
+    fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, G.tw1, parity);
+    cplx *dst = L.body_out + (size_t)e * L.plane + (size_t)P * d2;
+    const double inv = 1.0 / (double)N1;
+    double m2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n1 = v + (N1 / R) * i;
+        const long long idx = (long long)n1 * N2 + n2;
+        cplx val = x[i] * inv;
+        if (idx == 0) {
+            // tails of the two factors -> constant term of the product, un-alias coefficient 0
+            const double sA = L.scale_in[2 * P], sB = L.scale_in[2 * P + 1];
+            const int row = e >> 1, col = e & 1;
+            const cplx a0 = L.tail_in[(size_t)(2 * row) * L.n_in + 2 * P] * sA;
+            const cplx a1 = L.tail_in[(size_t)(2 * row + 1) * L.n_in + 2 * P] * sA;
+            const cplx b0 = L.tail_in[(size_t)(col)*L.n_in + 2 * P + 1] * sB;
+            const cplx b1 = L.tail_in[(size_t)(2 + col) * L.n_in + 2 * P + 1] * sB;
+            const cplx tp = cfma(a1, b1, a0 * b0);
+            if (N == d2) val = val - tp;
+            L.tail_out[(size_t)e * n_out + P] = tp;
+            m2 = fmax(m2, cnorm2(tp));
+        }
+        if (idx < d2) {
+            dst[idx] = val;
+            m2 = fmax(m2, cnorm2(val));
+        }
+    }
+    fa_atomic_max_u64(&L.max2_out[P], dbits(m2));
+}
+
+// one lane per output matrix: turn the maxima of the large path into pending scales
+FA_DEV void body_finalize_scales(const TreeLevel &L)
+{
+    const long long P = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (P >= L.n_in / 2) return;
+    const double m2 = bitsd(L.max2_out[P]);
+    int a = 0;
+    if (m2 > 0.0 && m2 < 1.0e300) a = half_exponent(m2);
+    L.scale_out[P] = pow2i(-a);
+    L.max2_out[P] = 0ull;
+    if (a != 0) fa_atomic_add_i32(&L.W[P / L.pairs_per_signal], a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// final transfer matrix in the reference's result layout (fnft__poly_fmult.c:522-538):
+// [r11|r12|r21|r22], each deg+1 coefficients, highest power first; deg = D*deg0 (the identity
+// padding contributes trailing zero coefficients which are dropped).
+// ---------------------------------------------------------------------------------------------
+struct ExportParams {
+    const cplx *body;   // 4 planes; signal b's matrix at b*deg_tot
+    const cplx *tail;   // 4 planes of batch
+    const double *scale;
+    cplx *out;          // batch * 4*(deg+1)
+    size_t plane;
+    long long deg_tot;  // Dpad*deg0
+    long long deg;      // D*deg0
+    int batch;
+};
+FA_DEV void body_export_tm(const ExportParams &E)
+{
+    const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long per = 4 * (E.deg + 1);
+    if (gid >= per * E.batch) return;
+    const int b = (int)(gid / per);
+    const long long r = gid % per;
+    const int e = (int)(r / (E.deg + 1));
+    const long long k = r % (E.deg + 1);
+    const double sc = E.scale[b];
+    cplx val;
+    if (k < E.deg_tot) val = E.body[(size_t)e * E.plane + (size_t)b * E.deg_tot + k];
+    else val = E.tail[(size_t)e * E.batch + b];
+    E.out[gid] = val * sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// chirp z-transform (fnft__poly_chirpz.c:52-95) of the a- and b-polynomials + spectrum epilogue
+// (fnft_nsev.c:837-884).  Transform length Lc = N1*N2 as above.
+// cpow(z, x) for real x is evaluated as exp(x*log z) like libm does, with log z formed on the
+// host (so that a |z| that is not exactly 1 after rounding has the same effect as in the
+// reference).
+// ---------------------------------------------------------------------------------------------
+struct ChirpParams {
+    // polynomials: entries 11 (slot 0) and 21 (slot 1) of the final transfer matrix, or an
+    // explicit coefficient array for the stand-alone fnft__poly_chirpz entry point
+    const cplx *body;    // 4 planes (tree result) or NULL
+    const cplx *tail;
+    const double *scale;
+    const cplx *poly;    // explicit polynomial(s): npoly * (deg+1), highest first, or NULL
+    size_t plane;
+    long long deg_tot;   // Dpad*deg0 (tree layout)
+    long long deg;       // polynomial degree actually evaluated
+    int batch;
+    int npoly;           // polynomials per signal (2 for nsev, 1 for stand-alone)
+    int entry[2];        // transfer-matrix entries to evaluate (0..3)
+    // chirp
+    double logA[2], logW[2];  // log A, log W (complex)
+    long long M;
+    int N1, N2;          // Lc = N1*N2
+    cplx *Ybuf;          // batch*npoly*Lc
+    cplx *Vbuf;          // Lc
+    cplx *Hbuf;          // stand-alone: output M per polynomial (host copies)
+    BigTwiddle btw;
+    const cplx *tw1, *tw2;
+    // epilogue
+    cplx *contspec;      // batch * cs_len
+    const int *W;        // per signal
+    int *status;         // bit 1: division by zero
+    double xi0, eps_xi, pf_rho, pf_a, pf_b;
+    int cstype;          // fnft_nsev_cstype_t ordinal, or -1: raw H values to Hbuf
+    int use_W;
+    int jobs_per_group;  // row step: jobs handled by one workgroup (grid.y = ceil(jobs/this))
+};
+
+// exp((xr + i*xi)) with a real multiplier folded in: returns exp(t*lr) * cis(t*li)
+FA_DEV cplx cpow_real(const double lg[2], double t)
+{
+    double s, c;
+    fa_sincos(t * lg[1], &s, &c);
+    const double mag = (lg[0] == 0.0) ? 1.0 : exp(t * lg[0]);
+    return cmake(mag * c, mag * s);
+}
+
+FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k)
+{
+    // coefficient k (highest power first) of polynomial `slot` of signal b
+    if (C.poly) return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)k];
+    const int e = C.entry[slot];
+    const double sc = C.scale[b];
+    if (k < C.deg_tot) return C.body[(size_t)e * C.plane + (size_t)b * C.deg_tot + k] * sc;
+    return C.tail[(size_t)e * C.batch + b] * sc;
+}
+
+// column step (forward) of the chirp-premultiplied polynomials and of the chirp filter
+//   grid.x = N2/BC, grid.y = batch*npoly + 1 (the last one is the filter v)
+template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_fwd(const ChirpParams &C)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int job = FA_BID_Y;
+    const int njobs = C.batch * C.npoly;
+    const long long Lc = (long long)N1 * C.N2;
+    const long long Np = C.deg + 1;
+    cplx x[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n1 = v + (N1 / R) * i;
+        const long long n = (long long)n1 * C.N2 + n2;
+        cplx val = cmake(0.0, 0.0);
+        const double dn = (double)n;
+        if (job < njobs) {
+            if (n < Np) {  // :68-69  p[deg-n] * A^-n * W^(n^2/2)
+                const cplx pc = chirp_poly_coef(C, job / C.npoly, job % C.npoly, C.deg - n);
+                val = pc * cpow_real(C.logA, -dn) * cpow_real(C.logW, 0.5 * dn * dn);
+            }
+        } else {  // :76-82
+            if (n < C.M) val = cpow_real(C.logW, -0.5 * dn * dn);
+            else if (n > Lc - Np) {
+                const double dm = (double)(Lc - n);
+                val = cpow_real(C.logW, -0.5 * dm * dm);
+            }
+        }
+        x[i] = val;
+    }
+    int parity = 0;
+    fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, C.tw1, parity);
+    cplx *dst = (job < njobs) ? C.Ybuf + (size_t)job * Lc : C.Vbuf;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int k1 = v + (N1 / R) * i;
+        const cplx w = big_twiddle(C.btw, (unsigned)k1 * (unsigned)n2);
+        dst[(size_t)k1 * C.N2 + n2] = x[i] * w;
+    }
+}
+
+// row step: per k1: V row forward; for each job of the group: Y row forward, * V, inverse,
+// store in place.   grid.x = N1, grid.y = job groups; one workgroup of N2/R lanes
+template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams &C)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const int v = FA_TID;
+    const int k1 = FA_BID;
+    const long long Lc = (long long)C.N1 * N2;
+    int parity = 0;
+    cplx vv[R];
+    const cplx *vs = C.Vbuf + (size_t)k1 * N2;
+#pragma unroll
+    for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i];
+    fft_wg<N2, R, 1, -1, DB>(vv, lds, v, 0, C.tw2, parity);
+    const int njobs = C.batch * C.npoly;
+    const double inv = 1.0 / (double)N2;
+    const int job0 = FA_BID_Y * C.jobs_per_group;
+    const int job1 = (job0 + C.jobs_per_group < njobs) ? job0 + C.jobs_per_group : njobs;
+    for (int job = job0; job < job1; job++) {
+        cplx *ys = C.Ybuf + (size_t)job * Lc + (size_t)k1 * N2;
+        cplx y[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) y[i] = ys[v + (N2 / R) * i];
+        fft_wg<N2, R, 1, -1, DB>(y, lds, v, 0, C.tw2, parity);
+#pragma unroll
+        for (int i = 0; i < R; i++) y[i] = y[i] * vv[i];
+        fft_wg<N2, R, 1, +1, DB>(y, lds, v, 0, C.tw2, parity);
+#pragma unroll
+        for (int i = 0; i < R; i++) ys[v + (N2 / R) * i] = y[i] * inv;
+    }
+}
+
+// column step (inverse) + chirp post-multiplication + spectrum epilogue
+//   grid.x = N2/BC, grid.y = batch
+template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const ChirpParams &C)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int b = FA_BID_Y;
+    const long long Lc = (long long)N1 * C.N2;
+    const double inv = 1.0 / (double)N1;
+    cplx H[2][R];
+    int parity = 0;
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++) {
+        if (slot >= C.npoly) {
+#pragma unroll
+            for (int i = 0; i < R; i++) H[slot][i] = cmake(0.0, 0.0);
+            continue;
+        }
+        const cplx *src = C.Ybuf + ((size_t)b * C.npoly + slot) * Lc;
+        cplx x[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int k1 = v + (N1 / R) * i;
+            const cplx w = cconj(big_twiddle(C.btw, (unsigned)k1 * (unsigned)n2));
+            x[i] = src[(size_t)k1 * C.N2 + n2] * w;
+        }
+        fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, C.tw1, parity);
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int n1 = v + (N1 / R) * i;
+            const long long m = (long long)n1 * C.N2 + n2;
+            const double dm = (double)m;
+            // :94-95  W^(m^2/2) * V[m] / L   (1/N2 was applied by the row step)
+            cplx h = cmake(0.0, 0.0);
+            if (m < C.M) h = (x[i] * inv) * cpow_real(C.logW, 0.5 * dm * dm);
+            H[slot][i] = h;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n1 = v + (N1 / R) * i;
+        const long long m = (long long)n1 * C.N2 + n2;
+        if (m >= C.M) continue;
+        if (C.cstype < 0) {  // raw chirp-z values
+#pragma unroll
+            for (int slot = 0; slot < 2; slot++)
+                if (slot < C.npoly)
+                    C.Hbuf[((size_t)b * C.npoly + slot) * (size_t)C.M + (size_t)m] = H[slot][i];
+            continue;
+        }
+        const double xi = C.xi0 + C.eps_xi * (double)m;  // fnft_nsev.c:784-785
+        const long long cs_len = C.M * (C.cstype == 0 ? 1 : (C.cstype == 1 ? 2 : 3));
+        cplx *out = C.contspec + (size_t)b * cs_len;
+        long long off = 0;
+        const cplx h11 = H[0][i], h21 = H[1][i];
+        if (C.cstype == 0 || C.cstype == 2) {  // :844-855
+            if (h11.x == 0.0 && h11.y == 0.0) {
+                fa_atomic_or_i32(C.status, 2);
+            } else {
+                double s, co;
+                fa_sincos(xi * C.pf_rho, &s, &co);
+                out[m] = c_div(h21 * cmake(co, s), h11);
+            }
+            off = C.M;
+        }
+        if (C.cstype == 1 || C.cstype == 2) {  // :861-876
+            const double scale = C.use_W ? ldexp(1.0, C.W[b]) : 1.0;
+            double s, co;
+            fa_sincos(xi * C.pf_a, &s, &co);
+            out[off + m] = (h11 * scale) * cmake(co, s);
+            fa_sincos(xi * C.pf_b, &s, &co);
+            out[off + C.M + m] = (h21 * scale) * cmake(co, s);
+        }
+    }
+}

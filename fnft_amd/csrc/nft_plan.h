@@ -1,0 +1,436 @@
+// nft_plan.h -- back-end independent host logic of the fnft_nsev continuous-spectrum path:
+// workspace layout in HBM, level schedule of the product tree, chirp z-transform set-up.
+//
+// Mirrors the control flow of the reference (file:line relative to the FNFT source tree):
+//   fnft_nsev_base           src/fnft_nsev.c:458-565
+//   nse_fscatter             src/private/fnft__nse_fscatter.c:44-91
+//   akns_fscatter            src/private/fnft__akns_fscatter.c:64-925
+//   poly_fmult2x2            src/private/fnft__poly_fmult.c:381-546
+//   nsev_compute_contspec    src/fnft_nsev.c:744-891
+//   poly_chirpz              src/private/fnft__poly_chirpz.c:33-105
+//
+// BE (back end) supplies device memory, copies, kernel launches and stage timers; see
+// hip_backend.hip (product) and tests/emu/emu_backend.h (CPU lane emulator, tests only).
+#pragma once
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "nft_dispatch.h"
+
+// return codes (include/fnft_errwarn.h:44-94)
+enum {
+    NFT_SUCCESS = 0, NFT_EC_NOMEM = 1, NFT_EC_INVALID_ARGUMENT = 2, NFT_EC_DIV_BY_ZERO = 3,
+    NFT_EC_OTHER = 5, NFT_EC_NOT_YET_IMPLEMENTED = 6
+};
+
+inline size_t nft_nextpow2(size_t n)
+{
+    size_t r = 1;
+    while (r < n) r *= 2;
+    return r;
+}
+inline int nft_log2(size_t n)
+{
+    int l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+// fnft__akns_discretization.c:29-67 restricted to what the coefficient kernel implements
+inline int nft_akns_degree(int akns_disc)
+{
+    switch (akns_disc) {
+    case 0: case 1: case 2: case 3: case 4: case 5: return 1;   // MODAL,1A,1B,2A,2B,2S
+    case 8: case 10: return 2;                                   // 3S, 4B
+    case 6: case 7: return 3;                                    // 3A, 3B
+    case 9: return 4;                                            // 4A
+    default: return 0;
+    }
+}
+// fnft__nse_discretization.c:108-200 (upsampling-factor-1 schemes of degree <= 4); -1 otherwise
+inline int nft_nse_to_akns(int nse_disc)
+{
+    switch (nse_disc) {
+    case 0: return 0;    // 2SPLIT2_MODAL
+    case 2: return 1;    // 2SPLIT1A
+    case 3: return 2;    // 2SPLIT1B
+    case 4: return 3;    // 2SPLIT2A
+    case 5: return 4;    // 2SPLIT2B
+    case 6: return 5;    // 2SPLIT2S
+    case 7: return 6;    // 2SPLIT3A
+    case 8: return 7;    // 2SPLIT3B
+    case 9: return 8;    // 2SPLIT3S
+    case 10: return 9;   // 2SPLIT4A
+    case 11: return 10;  // 2SPLIT4B
+    default: return -1;
+    }
+}
+
+// transform length used for a product of two degree-d polynomials
+inline size_t nft_product_len(size_t d)
+{
+    const size_t p = nft_nextpow2(2 * d);
+    return (p == 2 * d) ? p : nft_nextpow2(2 * d + 1);
+}
+
+constexpr int kFineLog2 = 12;           // master twiddle: NMAX = 2^24
+constexpr int kMaxTwTable = 4096;       // per-length tables up to this length
+constexpr size_t kMaxSplitN = (size_t)kRowLen * 1024;
+
+template <class BE> class NftPlan {
+public:
+    BE &be;
+    size_t D, M, batch;
+    int akns_disc, deg0;
+    size_t Dpad, plane, n0;
+
+    // device buffers
+    cplx *body[2] = {nullptr, nullptr};
+    cplx *tail[2] = {nullptr, nullptr};
+    double *scale[2] = {nullptr, nullptr};
+    unsigned long long *max2 = nullptr;
+    int *W = nullptr;
+    int *status = nullptr;
+    cplx *Y = nullptr, *Z = nullptr;
+    cplx *chY = nullptr, *chV = nullptr, *chH = nullptr;
+    cplx *tm_out = nullptr;
+    cplx *twtab = nullptr;   // concatenated tables for N = 2,4,...,kMaxTwTable
+    cplx *twlo = nullptr;    // exp(-2 pi i j / 2^24), j < 4096
+    size_t Lc = 0;           // chirp transform length
+    size_t bytes = 0;
+    int cur = 0;             // index of the body/tail/scale set holding the current level
+    bool tree_valid = false;
+    size_t res_deg = 0;      // degree of the transfer matrix of the last tree run
+
+    NftPlan(BE &be_, size_t D_, size_t M_, size_t batch_, int akns_disc_, int deg0_)
+        : be(be_), D(D_), M(M_), batch(batch_), akns_disc(akns_disc_), deg0(deg0_)
+    {
+        Dpad = nft_nextpow2(D);
+        n0 = batch * Dpad;
+        plane = n0 * (size_t)deg0;
+    }
+
+    template <class T> bool alloc(T *&p, size_t count)
+    {
+        const size_t b = count * sizeof(T);
+        p = (T *)be.alloc(b ? b : 16);
+        if (!p) return false;
+        bytes += b;
+        return true;
+    }
+
+    const cplx *tw_table(size_t N) const
+    {   // tables are stored back to back: N=2 at offset 0, N=4 at 2, N=8 at 6, ... offset = N-2
+        return twtab + (N - 2);
+    }
+    BigTwiddle big_tw(size_t N) const
+    {
+        BigTwiddle t;
+        t.hi = tw_table(kMaxTwTable);
+        t.lo = twlo;
+        t.fine_log2 = kFineLog2;
+        t.shift = 2 * kFineLog2 - nft_log2(N);
+        return t;
+    }
+
+    int init()
+    {
+        if (D < 1 || batch < 1 || deg0 < 1) return NFT_EC_INVALID_ARGUMENT;
+        // largest product transform of the tree and chirp length must be within the split limits
+        const size_t topN = (Dpad > 1) ? nft_product_len(Dpad / 2 * (size_t)deg0) : 2;
+        if (topN > kMaxSplitN) return NFT_EC_NOT_YET_IMPLEMENTED;
+        bool ok = true;
+        for (int i = 0; i < 2; i++) {
+            ok = ok && alloc(body[i], 4 * plane) && alloc(tail[i], 4 * n0) && alloc(scale[i], n0);
+        }
+        ok = ok && alloc(max2, n0) && alloc(W, batch) && alloc(status, 4);
+        if (topN > (size_t)kFusedMaxN) ok = ok && alloc(Y, 8 * plane) && alloc(Z, 4 * plane);
+        if (M > 0) {
+            const size_t Np = D * (size_t)deg0 + 1;
+            Lc = nft_nextpow2(Np + M - 1);
+            if (Lc < 2 * (size_t)kRowLen) Lc = 2 * (size_t)kRowLen;
+            if (Lc > kMaxSplitN) return NFT_EC_NOT_YET_IMPLEMENTED;
+            ok = ok && alloc(chY, batch * 2 * Lc) && alloc(chV, Lc);
+        }
+        ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
+        ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
+        if (!ok) return NFT_EC_NOMEM;
+        be.memset0(max2, n0 * sizeof(unsigned long long));
+        upload_twiddles();
+        return NFT_SUCCESS;
+    }
+
+    void destroy()
+    {
+        for (int i = 0; i < 2; i++) { be.free(body[i]); be.free(tail[i]); be.free(scale[i]); }
+        be.free(max2); be.free(W); be.free(status); be.free(Y); be.free(Z);
+        be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
+    }
+
+    void upload_twiddles()
+    {
+        std::vector<cplx> h((size_t)2 * kMaxTwTable);
+        const long double tau = 6.283185307179586476925286766559005768L;
+        for (size_t N = 2; N <= (size_t)kMaxTwTable; N *= 2)
+            for (size_t j = 0; j < N; j++) {
+                const long double a = -tau * (long double)j / (long double)N;
+                h[N - 2 + j] = cmake((double)cosl(a), (double)sinl(a));
+            }
+        be.h2d(twtab, h.data(), h.size() * sizeof(cplx));
+        std::vector<cplx> lo((size_t)1 << kFineLog2);
+        const long double nmax = (long double)((size_t)1 << (2 * kFineLog2));
+        for (size_t j = 0; j < lo.size(); j++) {
+            const long double a = -tau * (long double)j / nmax;
+            lo[j] = cmake((double)cosl(a), (double)sinl(a));
+        }
+        be.h2d(twlo, lo.data(), lo.size() * sizeof(cplx));
+    }
+
+    // ---- level 0 from samples (fnft__akns_fscatter.c:116-917) --------------------------------
+    int run_coeffs(const void *d_q, const void *d_r, double eps_t, int kappa)
+    {
+        be.memset0(W, batch * sizeof(int));
+        be.memset0(status, 4 * sizeof(int));
+        CoeffParams p;
+        p.q = (const cplx *)d_q;
+        p.r = (const cplx *)d_r;
+        p.body = body[0];
+        p.tail = tail[0];
+        p.scale = scale[0];
+        p.status = status;
+        p.plane = plane;
+        p.eps_t = eps_t;
+        p.D = (int)D;
+        p.Dpad = (int)Dpad;
+        p.batch = (int)batch;
+        p.kappa = kappa;
+        p.disc = akns_disc;
+        p.deg = deg0;
+        cur = 0;
+        if (!dispatch_coeffs(be, p)) return NFT_EC_NOT_YET_IMPLEMENTED;
+        return NFT_SUCCESS;
+    }
+
+    // ---- level 0 from explicit coefficient matrices in the reference layout (host) ------------
+    // p_host: [4][n*(deg0+1)], n = D matrices (fnft__poly_fmult.c:398-401)
+    int load_level0_from_host(const std::complex<double> *p_host)
+    {
+        std::vector<cplx> hb(4 * plane), ht(4 * n0);
+        std::vector<double> hs(n0, 1.0);
+        const size_t w = (size_t)deg0 + 1;
+        for (int e = 0; e < 4; e++)
+            for (size_t j = 0; j < Dpad; j++) {
+                for (size_t k = 0; k < w; k++) {
+                    cplx v = cmake(0.0, 0.0);
+                    if (j < D) {
+                        const std::complex<double> z = p_host[(size_t)e * D * w + j * w + k];
+                        v = cmake(z.real(), z.imag());
+                    } else if (k == 0 && (e == 0 || e == 3)) {
+                        v = cmake(1.0, 0.0);  // identity pad z^deg * I, fnft__poly_fmult.c:422-438
+                    }
+                    if (k < (size_t)deg0) hb[(size_t)e * plane + j * deg0 + k] = v;
+                    else ht[(size_t)e * n0 + j] = v;
+                }
+            }
+        be.h2d(body[0], hb.data(), hb.size() * sizeof(cplx));
+        be.h2d(tail[0], ht.data(), ht.size() * sizeof(cplx));
+        be.h2d(scale[0], hs.data(), hs.size() * sizeof(double));
+        be.memset0(W, batch * sizeof(int));
+        be.memset0(status, 4 * sizeof(int));
+        cur = 0;
+        return NFT_SUCCESS;
+    }
+
+    // ---- product tree (fnft__poly_fmult.c:460-519) ---------------------------------------------
+    int run_tree()
+    {
+        size_t n = n0;          // matrices at the current level, all signals
+        size_t d = (size_t)deg0;
+        while (n / batch > 1) {
+            TreeLevel L;
+            L.body_in = body[cur]; L.tail_in = tail[cur]; L.scale_in = scale[cur];
+            L.body_out = body[cur ^ 1]; L.tail_out = tail[cur ^ 1]; L.scale_out = scale[cur ^ 1];
+            L.max2_out = max2;
+            L.W = W;
+            L.plane = plane;
+            L.n_in = (int)n;
+            L.d = (int)d;
+            L.pairs_per_signal = (int)(n / 2 / batch);
+            const size_t N = nft_product_len(d);
+            L.tw = (N <= (size_t)kMaxTwTable) ? tw_table(N) : nullptr;
+            bool ok;
+            if (d <= (size_t)kSchoolMaxDeg) {
+                ok = dispatch_pair_school(be, L);
+            } else if (N <= (size_t)kFusedMaxN) {
+                ok = dispatch_pair_fft(be, L, (int)N);
+            } else {
+                BigLevel G;
+                G.L = L;
+                G.Y = Y; G.Z = Z;
+                G.N2 = kRowLen;
+                G.N1 = (int)(N / kRowLen);
+                G.btw = big_tw(N);
+                G.tw1 = (G.N1 >= 2) ? tw_table((size_t)G.N1) : nullptr;
+                G.tw2 = tw_table(kRowLen);
+                ok = dispatch_col_fwd(be, G);
+                if (ok) {
+                    be.template run<KMid>((int)(n / 2) * G.N1, 1, G);
+                    ok = dispatch_col_inv(be, G);
+                }
+                if (ok) be.template run<KFinalizeScales>((int)((n / 2 + 63) / 64), 1, L);
+            }
+            if (!ok) return NFT_EC_NOT_YET_IMPLEMENTED;
+            cur ^= 1;
+            n /= 2;
+            d *= 2;
+        }
+        res_deg = D * (size_t)deg0;
+        tree_valid = true;
+        return NFT_SUCCESS;
+    }
+
+    // ---- result in the reference layout (fnft__poly_fmult.c:522-538) ---------------------------
+    void export_tm()
+    {
+        ExportParams E;
+        E.body = body[cur]; E.tail = tail[cur]; E.scale = scale[cur];
+        E.out = tm_out;
+        E.plane = plane;
+        E.deg_tot = (long long)(Dpad * (size_t)deg0);
+        E.deg = (long long)res_deg;
+        E.batch = (int)batch;
+        const long long tot = 4 * (E.deg + 1) * E.batch;
+        be.template run<KExportTm>((int)((tot + 255) / 256), 1, E);
+    }
+
+    // ---- chirp z + epilogue (fnft_nsev.c:744-891) ----------------------------------------------
+    struct Contspec {
+        double T[2], XI[2];
+        int nse_disc;
+        int cstype;
+        int normalization_flag;
+    };
+
+    void fill_chirp_geometry(ChirpParams &C, size_t L)
+    {
+        C.N2 = kRowLen;
+        C.N1 = (int)(L / kRowLen);
+        C.btw = big_tw(L);
+        C.tw1 = tw_table((size_t)C.N1);
+        C.tw2 = tw_table(kRowLen);
+        C.jobs_per_group = 2;
+    }
+
+    int run_contspec(void *d_contspec, const Contspec &cs)
+    {
+        const double deg1 = (double)deg0;
+        const double eps_t = (cs.T[1] - cs.T[0]) / (double)(D - 1);
+        const double eps_xi = (cs.XI[1] - cs.XI[0]) / (double)(M - 1);
+        // lambda -> z, fnft__akns_discretization.c:204-219 called from fnft_nsev.c:822-827
+        const double phiV = 2.0 * eps_xi * eps_t / deg1;
+        const double phiA = 2.0 * (-cs.XI[0]) * eps_t / deg1;
+        const std::complex<double> V(std::cos(phiV), std::sin(phiV));
+        const std::complex<double> A(std::cos(phiA), std::sin(phiA));
+        const std::complex<double> lV = std::log(V), lA = std::log(A);
+
+        ChirpParams C;
+        std::memset(&C, 0, sizeof(C));
+        C.body = body[cur]; C.tail = tail[cur]; C.scale = scale[cur];
+        C.poly = nullptr;
+        C.plane = plane;
+        C.deg_tot = (long long)(Dpad * (size_t)deg0);
+        C.deg = (long long)res_deg;
+        C.batch = (int)batch;
+        C.npoly = 2;
+        C.entry[0] = 0;  // H11, fnft_nsev.c:829
+        C.entry[1] = 2;  // H21, fnft_nsev.c:832
+        C.logA[0] = lA.real(); C.logA[1] = lA.imag();
+        C.logW[0] = lV.real(); C.logW[1] = lV.imag();
+        C.M = (long long)M;
+        C.Ybuf = chY; C.Vbuf = chV; C.Hbuf = nullptr;
+        fill_chirp_geometry(C, Lc);
+        C.contspec = (cplx *)d_contspec;
+        C.W = W;
+        C.status = status;
+        C.xi0 = cs.XI[0];
+        C.eps_xi = eps_xi;
+        // phase factors, fnft__nse_discretization.c:240-379, boundary coefficient 0.5
+        const double bc = 0.5;
+        const bool shifted = (cs.nse_disc == 0 /*MODAL*/ || cs.nse_disc == 4 /*2SPLIT2A*/);
+        C.pf_rho = -2.0 * (cs.T[1] + eps_t * bc) + (shifted ? eps_t / deg1 : 0.0);
+        C.pf_a = -eps_t * (double)D + (cs.T[1] + eps_t * bc) - (cs.T[0] - eps_t * bc);
+        C.pf_b = -eps_t * (double)D - (cs.T[1] + eps_t * bc) - (cs.T[0] - eps_t * bc)
+                 + (shifted ? eps_t / deg1 : 0.0);
+        C.cstype = cs.cstype;
+        C.use_W = 1;  // W is the exponent actually taken out, whatever normalization_flag says
+        return run_chirp(C);
+    }
+
+    int run_chirp(const ChirpParams &C)
+    {
+        if (!dispatch_chirp_col_fwd(be, C)) return NFT_EC_NOT_YET_IMPLEMENTED;
+        const int njobs = C.batch * C.npoly;
+        be.template run<KChirpRows>(C.N1, (njobs + C.jobs_per_group - 1) / C.jobs_per_group, C);
+        if (!dispatch_chirp_col_inv(be, C)) return NFT_EC_NOT_YET_IMPLEMENTED;
+        return NFT_SUCCESS;
+    }
+
+    // stand-alone chirp z-transform of one host polynomial (fnft__poly_chirpz.c:33-105)
+    static int chirpz_host(BE &be, size_t deg, const std::complex<double> *p,
+                           std::complex<double> A, std::complex<double> Wc, size_t Mo,
+                           std::complex<double> *result)
+    {
+        NftPlan pl(be, 2, 0, 1, 0, 1);  // only the twiddle tables of the plan are used
+        size_t L = nft_nextpow2(deg + 1 + Mo - 1);
+        if (L < 2 * (size_t)kRowLen) L = 2 * (size_t)kRowLen;
+        if (L > kMaxSplitN) return NFT_EC_NOT_YET_IMPLEMENTED;
+        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, (size_t)1 << kFineLog2);
+        cplx *dp = nullptr, *dY = nullptr, *dV = nullptr, *dH = nullptr;
+        int *dstatus = nullptr;
+        ok = ok && pl.alloc(dp, deg + 1) && pl.alloc(dY, L) && pl.alloc(dV, L) && pl.alloc(dH, Mo)
+             && pl.alloc(dstatus, 4);
+        int rc = NFT_EC_NOMEM;
+        if (ok) {
+            pl.upload_twiddles();
+            be.h2d(dp, p, (deg + 1) * sizeof(cplx));
+            be.memset0(dstatus, 4 * sizeof(int));
+            const std::complex<double> lA = std::log(A), lW = std::log(Wc);
+            ChirpParams C;
+            std::memset(&C, 0, sizeof(C));
+            C.poly = dp;
+            C.deg = (long long)deg;
+            C.batch = 1;
+            C.npoly = 1;
+            C.logA[0] = lA.real(); C.logA[1] = lA.imag();
+            C.logW[0] = lW.real(); C.logW[1] = lW.imag();
+            C.M = (long long)Mo;
+            C.Ybuf = dY; C.Vbuf = dV; C.Hbuf = dH;
+            pl.fill_chirp_geometry(C, L);
+            C.status = dstatus;
+            C.cstype = -1;
+            rc = pl.run_chirp(C);
+            if (rc == NFT_SUCCESS) {
+                be.d2h(result, dH, Mo * sizeof(cplx));
+                rc = be.sync();
+            }
+        }
+        be.free(dp); be.free(dY); be.free(dV); be.free(dH); be.free(dstatus);
+        be.free(pl.twtab); be.free(pl.twlo);
+        return rc;
+    }
+
+    // device-side status word -> return code (after the stream has been waited for)
+    int read_status()
+    {
+        int h[4] = {0, 0, 0, 0};
+        be.d2h(h, status, sizeof(h));
+        const int rc = be.sync();
+        if (rc != NFT_SUCCESS) return rc;
+        if (h[0] & 1) return -NFT_EC_OTHER;        // fnft__akns_fscatter.c:122-126 via CHECK_RETCODE
+        if (h[0] & 2) return -NFT_EC_DIV_BY_ZERO;  // fnft_nsev.c:850-853 via CHECK_RETCODE
+        return NFT_SUCCESS;
+    }
+};

@@ -1,0 +1,261 @@
+/*
+ * fnft_amd.h -- C ABI of libfnft_amd.so: the MI355X-native fast nonlinear Fourier transform
+ * (continuous spectrum of the NSE with vanishing boundaries).
+ *
+ * Section 1 is the DROP-IN boundary: the same symbols, argument meaning, ownership rules and
+ * return codes as the reference's libfnft.so, so a caller of the reference relinks against
+ * libfnft_amd.so unchanged.  Every declaration cites the reference interface it replaces
+ * (file:line relative to the FNFT source tree).
+ * Section 2 is the optional second seam (the reference's exported private layer).
+ * Section 3 is the device-resident extension used when inputs already live in HBM.
+ *
+ * Plain pointers and sizes only; no framework types.
+ */
+#ifndef FNFT_AMD_H
+#define FNFT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#include <complex>
+typedef std::complex<double> FNFT_COMPLEX; /* include/fnft_numtypes.h:47-50 */
+extern "C" {
+#else
+#include <complex.h>
+typedef double complex FNFT_COMPLEX; /* include/fnft_numtypes.h:47-50 */
+#endif
+
+typedef double FNFT_REAL; /* include/fnft_numtypes.h:40 */
+typedef int32_t FNFT_INT; /* include/fnft_numtypes.h:56 */
+typedef size_t FNFT_UINT; /* include/fnft_numtypes.h:62 */
+
+/* ---- return codes, include/fnft_errwarn.h:44-94 ------------------------------------------ */
+#define FNFT_SUCCESS 0
+#define FNFT_EC_NOMEM 1
+#define FNFT_EC_INVALID_ARGUMENT 2
+#define FNFT_EC_DIV_BY_ZERO 3
+#define FNFT_EC_TEST_FAILED 4
+#define FNFT_EC_OTHER 5
+#define FNFT_EC_NOT_YET_IMPLEMENTED 6
+#define FNFT_EC_SANITY_CHECK_FAILED 7
+#define FNFT_EC_ASSERTION_FAILED 8
+
+/* ---- error/warning text hook, include/fnft_errwarn.h:36,101,108 --------------------------- */
+typedef FNFT_INT (*fnft_printf_ptr_t)(const char *, ...);
+void fnft_errwarn_setprintf(fnft_printf_ptr_t printf_ptr);
+fnft_printf_ptr_t fnft_errwarn_getprintf(void);
+
+/* ---- discretizations, include/fnft_nse_discretization_t.h:104-133 (same ordinals) --------- */
+typedef enum {
+    fnft_nse_discretization_2SPLIT2_MODAL,
+    fnft_nse_discretization_BO,
+    fnft_nse_discretization_2SPLIT1A,
+    fnft_nse_discretization_2SPLIT1B,
+    fnft_nse_discretization_2SPLIT2A,
+    fnft_nse_discretization_2SPLIT2B,
+    fnft_nse_discretization_2SPLIT2S,
+    fnft_nse_discretization_2SPLIT3A,
+    fnft_nse_discretization_2SPLIT3B,
+    fnft_nse_discretization_2SPLIT3S,
+    fnft_nse_discretization_2SPLIT4A,
+    fnft_nse_discretization_2SPLIT4B,
+    fnft_nse_discretization_2SPLIT5A,
+    fnft_nse_discretization_2SPLIT5B,
+    fnft_nse_discretization_2SPLIT6A,
+    fnft_nse_discretization_2SPLIT6B,
+    fnft_nse_discretization_2SPLIT7A,
+    fnft_nse_discretization_2SPLIT7B,
+    fnft_nse_discretization_2SPLIT8A,
+    fnft_nse_discretization_2SPLIT8B,
+    fnft_nse_discretization_4SPLIT4A,
+    fnft_nse_discretization_4SPLIT4B,
+    fnft_nse_discretization_CF4_2,
+    fnft_nse_discretization_CF4_3,
+    fnft_nse_discretization_CF5_3,
+    fnft_nse_discretization_CF6_4,
+    fnft_nse_discretization_ES4,
+    fnft_nse_discretization_TES4
+} fnft_nse_discretization_t;
+
+/* include/private/fnft__akns_discretization_t.h:104-134 (same ordinals) */
+typedef enum {
+    fnft__akns_discretization_2SPLIT2_MODAL,
+    fnft__akns_discretization_2SPLIT1A,
+    fnft__akns_discretization_2SPLIT1B,
+    fnft__akns_discretization_2SPLIT2A,
+    fnft__akns_discretization_2SPLIT2B,
+    fnft__akns_discretization_2SPLIT2S,
+    fnft__akns_discretization_2SPLIT3A,
+    fnft__akns_discretization_2SPLIT3B,
+    fnft__akns_discretization_2SPLIT3S,
+    fnft__akns_discretization_2SPLIT4A,
+    fnft__akns_discretization_2SPLIT4B,
+    fnft__akns_discretization_2SPLIT5A,
+    fnft__akns_discretization_2SPLIT5B,
+    fnft__akns_discretization_2SPLIT6A,
+    fnft__akns_discretization_2SPLIT6B,
+    fnft__akns_discretization_2SPLIT7A,
+    fnft__akns_discretization_2SPLIT7B,
+    fnft__akns_discretization_2SPLIT8A,
+    fnft__akns_discretization_2SPLIT8B,
+    fnft__akns_discretization_BO,
+    fnft__akns_discretization_4SPLIT4A,
+    fnft__akns_discretization_4SPLIT4B,
+    fnft__akns_discretization_CF4_2,
+    fnft__akns_discretization_CF4_3,
+    fnft__akns_discretization_CF5_3,
+    fnft__akns_discretization_CF6_4,
+    fnft__akns_discretization_ES4,
+    fnft__akns_discretization_TES4
+} fnft__akns_discretization_t;
+
+/* ---- fnft_nsev options, include/fnft_nsev.h:51-55,91-95,108-112,130-134,198-208 ----------- */
+typedef enum {
+    fnft_nsev_bsfilt_NONE,
+    fnft_nsev_bsfilt_BASIC,
+    fnft_nsev_bsfilt_FULL
+} fnft_nsev_bsfilt_t;
+
+typedef enum {
+    fnft_nsev_bsloc_FAST_EIGENVALUE,
+    fnft_nsev_bsloc_NEWTON,
+    fnft_nsev_bsloc_SUBSAMPLE_AND_REFINE
+} fnft_nsev_bsloc_t;
+
+typedef enum {
+    fnft_nsev_dstype_NORMING_CONSTANTS,
+    fnft_nsev_dstype_RESIDUES,
+    fnft_nsev_dstype_BOTH
+} fnft_nsev_dstype_t;
+
+typedef enum {
+    fnft_nsev_cstype_REFLECTION_COEFFICIENT,
+    fnft_nsev_cstype_AB,
+    fnft_nsev_cstype_BOTH
+} fnft_nsev_cstype_t;
+
+typedef struct {
+    fnft_nsev_bsfilt_t bound_state_filtering;
+    fnft_nsev_bsloc_t bound_state_localization;
+    FNFT_UINT niter;
+    FNFT_UINT Dsub;
+    fnft_nsev_dstype_t discspec_type;
+    fnft_nsev_cstype_t contspec_type;
+    FNFT_INT normalization_flag;
+    fnft_nse_discretization_t discretization;
+    FNFT_UINT richardson_extrapolation_flag;
+} fnft_nsev_opts_t;
+
+/* ======================================================================================== */
+/* 1. Drop-in boundary                                                                      */
+/* ======================================================================================== */
+
+/* include/fnft_nsev.h:226 -- defaults: FULL filtering, SUBSAMPLE_AND_REFINE, niter 10, Dsub 0,
+ * NORMING_CONSTANTS, REFLECTION_COEFFICIENT, normalization on, 2SPLIT4B, no Richardson
+ * (src/fnft_nsev.c:26-36). */
+fnft_nsev_opts_t fnft_nsev_default_opts(void);
+
+/* include/fnft_nsev.h:241-242 -- degree(discretization) * D (src/fnft_nsev.c:51-57). */
+FNFT_UINT fnft_nsev_max_K(const FNFT_UINT D, fnft_nsev_opts_t const *const opts);
+
+/* include/fnft_nsev.h:371-376.  All buffers are HOST memory owned by the caller:
+ *   q[D]; T[2]; XI[2]; contspec[M], [2M] or [3M] by opts->contspec_type (NULL: skip);
+ *   K_ptr / bound_states / normconsts_or_residues: discrete spectrum.
+ * This build computes the continuous spectrum on the GPU.  A call that asks for the discrete
+ * spectrum (kappa == +1 and bound_states != NULL) returns FNFT_EC_NOT_YET_IMPLEMENTED; every
+ * other argument error returns the code the reference returns, checked in the same order
+ * (src/fnft_nsev.c:163-220). */
+FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *const T,
+                   const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI,
+                   FNFT_UINT *const K_ptr, FNFT_COMPLEX *const bound_states,
+                   FNFT_COMPLEX *const normconsts_or_residues, const FNFT_INT kappa,
+                   fnft_nsev_opts_t *opts);
+
+/* ======================================================================================== */
+/* 2. Private-layer seam (symbols the reference's libfnft.so also exports)                  */
+/* ======================================================================================== */
+
+/* include/private/fnft__poly_fmult.h:199 -- 4*(deg+1)*nextpow2(n) */
+FNFT_UINT fnft__poly_fmult2x2_numel(const FNFT_UINT deg, const FNFT_UINT n);
+
+/* include/private/fnft__poly_fmult.h:223-224 (src/private/fnft__poly_fmult.c:381-546).
+ * Host buffers; p = [p11|p12|p21|p22], each n*(deg+1), is overwritten; result receives
+ * [r11|r12|r21|r22], each (*d)+1 on return; *W_ptr (if non-NULL) receives the power-of-two
+ * exponent with  true product = result * 2^W. */
+FNFT_INT fnft__poly_fmult2x2(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *const p,
+                             FNFT_COMPLEX *const result, FNFT_INT *const W_ptr);
+
+/* include/private/fnft__poly_chirpz.h:61 (src/private/fnft__poly_chirpz.c:33-105).
+ * A and W are passed as pointers to {re, im} here (complex-by-value does not cross every FFI);
+ * fnft__poly_chirpz below is the by-value form with the reference's exact signature. */
+FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p,
+                              const double *A_reim, const double *W_reim, const FNFT_UINT M,
+                              FNFT_COMPLEX *const result);
+FNFT_INT fnft__poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const FNFT_COMPLEX A,
+                           const FNFT_COMPLEX W, const FNFT_UINT M, FNFT_COMPLEX *const result);
+
+/* include/private/fnft__akns_fscatter.h:57,89-90 (src/private/fnft__akns_fscatter.c:34-42,64-925) */
+FNFT_UINT fnft__akns_fscatter_numel(FNFT_UINT D, fnft__akns_discretization_t discretization);
+FNFT_INT fnft__akns_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q,
+                             FNFT_COMPLEX const *const r, const FNFT_REAL eps_t,
+                             FNFT_COMPLEX *const result, FNFT_UINT *const deg_ptr,
+                             FNFT_INT *const W_ptr, fnft__akns_discretization_t discretization);
+
+/* include/private/fnft__nse_fscatter.h:49,81-84 (src/private/fnft__nse_fscatter.c:34-91) */
+FNFT_UINT fnft__nse_fscatter_numel(FNFT_UINT D, fnft_nse_discretization_t discretization);
+FNFT_INT fnft__nse_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q, const FNFT_REAL eps_t,
+                            const FNFT_INT kappa, FNFT_COMPLEX *const result,
+                            FNFT_UINT *const deg_ptr, FNFT_INT *const W_ptr,
+                            fnft_nse_discretization_t discretization);
+
+/* ======================================================================================== */
+/* 3. Device-resident extension (no counterpart in the reference: it has no device path)    */
+/* ======================================================================================== */
+
+typedef struct fnft_amd_plan fnft_amd_plan_t;
+
+/* Number of HIP devices visible; <0 on HIP failure. */
+int fnft_amd_device_count(void);
+/* Last HIP error text of the calling thread ("" if none). */
+const char *fnft_amd_last_error(void);
+
+/* Plan for `batch` independent signals of D samples each, M spectral points, one
+ * discretization.  Allocates every workspace the call needs in HBM once. */
+FNFT_INT fnft_amd_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
+                              fnft_nse_discretization_t discretization, int device);
+void fnft_amd_plan_destroy(fnft_amd_plan_t *plan);
+/* Bytes of HBM the plan holds. */
+FNFT_UINT fnft_amd_plan_workspace_bytes(const fnft_amd_plan_t *plan);
+
+/* Continuous spectrum of batch signals, everything resident in HBM:
+ *   d_q:        batch*D complex128 (device), signal b at d_q + b*D
+ *   d_contspec: batch*cs_len complex128 (device), cs_len = M*{1,2,3} by contspec_type, layout per
+ *               signal as fnft_nsev writes it ([rho], [a b] or [rho a b]).
+ * stream is a hipStream_t passed as void* (NULL = default stream).  Asynchronous: returns after
+ * enqueueing; fnft_amd_plan_finish() waits and returns the device-side status
+ * (FNFT_SUCCESS, -FNFT_EC_DIV_BY_ZERO, -FNFT_EC_OTHER for the MODAL step-size check). */
+FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, void *d_contspec,
+                                       const FNFT_REAL *T, const FNFT_REAL *XI, FNFT_INT kappa,
+                                       fnft_nsev_cstype_t contspec_type,
+                                       FNFT_INT normalization_flag, void *stream);
+FNFT_INT fnft_amd_plan_finish(fnft_amd_plan_t *plan, void *stream);
+
+/* Time (ms) the product tree / the chirp-z+epilogue stage took in the last finished call,
+ * measured with HIP events on the stream the kernels ran on.  which: 0 = coefficients + tree,
+ * 1 = chirp-z + epilogue, 2 = whole call. */
+double fnft_amd_plan_last_ms(const fnft_amd_plan_t *plan, int which);
+/* Enable/disable the per-stage event timers (they add two event records per stage). */
+void fnft_amd_plan_set_timing(fnft_amd_plan_t *plan, int enabled);
+
+/* Transfer matrix of the last call (device pointers into the plan's workspace, signal b):
+ * coefficient arrays in the reference's result layout [r11|r12|r21|r22], each deg+1, highest
+ * power first, exponent W with true = stored * 2^W.  Copies to HOST buffers. */
+FNFT_INT fnft_amd_plan_get_transfer_matrix(fnft_amd_plan_t *plan, FNFT_UINT b,
+                                           FNFT_COMPLEX *result_host, FNFT_UINT *deg,
+                                           FNFT_INT *W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FNFT_AMD_H */

@@ -1,0 +1,161 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/fnft_amd.h
+declares, mirrors the reference's option defaults and argument validation (src/fnft_nsev.c:163-220)
+-- all of which return before any GPU work -- and fails loudly (never falls back) without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from fnft_amd import build, capi as c
+    build.build()
+    c.load()
+    c.silence_errors()
+    return c
+
+
+def test_exports_every_declared_symbol(capi):
+    hdr = open(os.path.join(ROOT, "include", "fnft_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fnft_\w+|fnft__\w+)\s*\(", hdr))
+    declared -= {"fnft_printf_ptr_t"}
+    L = capi.load()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(capi.EXPORTED) <= declared
+
+
+def test_default_opts_match_reference(capi):
+    # src/fnft_nsev.c:26-36
+    o = capi.default_opts()
+    assert (o.bound_state_filtering, o.bound_state_localization, o.niter, o.Dsub) == (2, 2, 10, 0)
+    assert (o.discspec_type, o.contspec_type, o.normalization_flag) == (0, 0, 1)
+    assert o.discretization == capi.NSE_DISC["2SPLIT4B"]
+    assert o.richardson_extrapolation_flag == 0
+    import ctypes
+    assert ctypes.sizeof(capi.NsevOpts) == 48
+
+
+def test_max_K_and_numel(capi):
+    L = capi.load()
+    assert L.fnft_nsev_max_K(100, None) == 200                     # default 2SPLIT4B, degree 2
+    o = capi.default_opts()
+    o.discretization = capi.NSE_DISC["2SPLIT2_MODAL"]
+    assert L.fnft_nsev_max_K(100, o) == 100
+    o.discretization = capi.NSE_DISC["2SPLIT7A"]
+    assert L.fnft_nsev_max_K(3, o) == 315
+    # src/private/fnft__poly_fmult.c:40-43 : 4*(deg+1)*nextpow2(n)
+    assert L.fnft__poly_fmult2x2_numel(1, 5) == 4 * 2 * 8
+    assert L.fnft__nse_fscatter_numel(1000, capi.NSE_DISC["2SPLIT4B"]) == 4 * 3 * 1024
+    assert L.fnft__nse_fscatter_numel(1000, capi.NSE_DISC["BO"]) == 0
+    assert L.fnft__akns_fscatter_numel(8, capi.AKNS_DISC["2SPLIT4A"]) == 4 * 5 * 8
+
+
+def test_validation_order_and_codes(capi):
+    """Same checks in the same order as src/fnft_nsev.c:163-178; each returns
+    FNFT_EC_INVALID_ARGUMENT (2) before anything else is looked at."""
+    import ctypes as C
+    L = capi.load()
+    q = np.ones(8, np.complex128)
+    T = np.array([0.0, 1.0])
+    XI = np.array([-1.0, 1.0])
+    cs = np.zeros(24, np.complex128)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    call = lambda D, qq, TT, M, c, X, kappa, K=None, bs=None: L.fnft_nsev(  # noqa: E731
+        D, qq, TT, M, c, X, K, bs, None, kappa, None)
+    assert call(1, None, None, 4, P(cs), None, 5) == 2          # D first
+    assert call(8, None, None, 4, P(cs), None, 5) == 2          # then q
+    assert call(8, P(q), None, 4, P(cs), None, 5) == 2          # then T
+    bad_T = np.array([1.0, 1.0])
+    assert call(8, P(q), P(bad_T), 4, P(cs), None, 5) == 2
+    assert call(8, P(q), P(T), 4, P(cs), None, 5) == 2          # XI (contspec given)
+    bad_XI = np.array([2.0, 1.0])
+    assert call(8, P(q), P(T), 4, P(cs), P(bad_XI), 5) == 2
+    assert call(8, P(q), P(T), 4, P(cs), P(XI), 0) == 2         # kappa
+    bs = np.zeros(16, np.complex128)
+    assert call(8, P(q), P(T), 4, P(cs), P(XI), 1, None, P(bs)) == 2   # K_ptr with bound_states
+
+
+def test_unknown_and_unsupported_options(capi):
+    q = np.ones(8, np.complex128)
+    o = capi.default_opts()
+    o.discretization = 99
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == 2                 # unknown discretization
+    o = capi.default_opts()
+    o.discretization = capi.NSE_DISC["BO"]                                        # slow scheme needs NEWTON
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == 2
+    o.bound_state_localization = 1
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    o = capi.default_opts()
+    o.discretization = capi.NSE_DISC["2SPLIT8B"]
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    o = capi.default_opts()
+    o.richardson_extrapolation_flag = 1
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    # discrete spectrum requested
+    bs = np.zeros(16, np.complex128)
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], bound_states=bs, K=16)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    o = capi.default_opts()
+    o.contspec_type = 7
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == -2                # wrapped twice like the reference
+
+
+def test_private_seam_argument_checks(capi):
+    import ctypes as C
+    L = capi.load()
+    q = np.ones(8, np.complex128)
+    res = np.zeros(64, np.complex128)
+    d = C.c_size_t(0)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    # src/private/fnft__akns_fscatter.c:80-97
+    assert L.fnft__akns_fscatter(0, P(q), P(q), 0.1, P(res), C.byref(d), None, 0) == 2
+    assert L.fnft__akns_fscatter(8, None, P(q), 0.1, P(res), C.byref(d), None, 0) == 2
+    assert L.fnft__akns_fscatter(8, P(q), P(q), 0.0, P(res), C.byref(d), None, 0) == 2
+    assert L.fnft__akns_fscatter(8, P(q), P(q), 0.1, P(res), C.byref(d), None, 19) == 2   # BO: no degree
+    # src/private/fnft__nse_fscatter.c:55-69
+    assert L.fnft__nse_fscatter(8, P(q), 0.1, 3, P(res), C.byref(d), None, 0) == 2
+    # src/private/fnft__poly_chirpz.c:44-49
+    one = (C.c_double * 2)(1.0, 0.0)
+    assert L.fnft_amd_poly_chirpz(3, None, one, one, 4, P(res)) == 2
+    assert L.fnft_amd_poly_chirpz(3, P(q), one, one, 0, P(res)) == 2
+
+
+def test_error_text_hook(capi):
+    """src/fnft_errwarn.c:52-60 + src/private/fnft__errwarn.c:28-37: messages go through the
+    user-settable printf; NULL disables them."""
+    import ctypes as C
+    L = capi.load()
+    seen = []
+    CB = C.CFUNCTYPE(C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                     C.c_char_p)
+
+    def hook(fmt, msg, func, line, a, b, c, suffix):
+        seen.append((fmt, msg, func))
+        return 0
+
+    cb = CB(hook)
+    L.fnft_errwarn_setprintf(C.cast(cb, C.c_void_p))
+    assert L.fnft_errwarn_getprintf() == C.cast(cb, C.c_void_p).value
+    assert L.fnft_nsev(1, None, None, 0, None, None, None, None, None, 1, None) == 2
+    L.fnft_errwarn_setprintf(None)
+    assert L.fnft_errwarn_getprintf() is None
+    assert seen and seen[0][0].startswith(b"FNFT Error: %s") and b"Invalid argument D" in seen[0][1]
+    assert seen[0][2] == b"fnft_nsev"
+
+
+def test_no_gpu_means_loud_failure(capi):
+    """Without a GPU the product path must fail (FNFT_EC_OTHER), never compute on the CPU."""
+    L = capi.load()
+    if L.fnft_amd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    q = np.ones(8, np.complex128)
+    rc, cs = capi.fnft_nsev(q, [0, 1], 4, [-1, 1])
+    assert rc == capi.FNFT_EC_OTHER and not np.any(cs)
+    assert capi.poly_fmult2x2(1, 2, np.ones((4, 4), np.complex128))[0] == capi.FNFT_EC_OTHER
+    with pytest.raises(RuntimeError):
+        capi.Plan(64, 16)

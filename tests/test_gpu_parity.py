@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle and the
+reference's known-answer vectors.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (floating point, fp64): the reference's own unit tests use rel-L1 <= 100*eps at toy
+sizes; for full transforms SURVEY.md section 8c gives GPU-vs-CPU rel-L1 bounds on a/b/rho of
+1e-12 (D <= 2^12), 2e-11 (D <= 2^16), 5e-10 (D = 2^20) -- about 8x the reference's own distance
+from the exact answer at those sizes.
+"""
+import numpy as np
+import pytest
+
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+AKNS_SCHEMES = ["2SPLIT2_MODAL", "2SPLIT1A", "2SPLIT1B", "2SPLIT2A", "2SPLIT2B", "2SPLIT2S",
+                "2SPLIT3A", "2SPLIT3B", "2SPLIT3S", "2SPLIT4A", "2SPLIT4B"]
+
+
+def tol_for(D):
+    if D <= 4096:
+        return 1e-12
+    if D <= 65536:
+        return 2e-11
+    return 5e-10
+
+
+@pytest.fixture(scope="module")
+def capi(lib):
+    from fnft_amd import capi as c
+    assert lib.fnft_amd_device_count() >= 1, c.last_error()
+    return c
+
+
+# ---- reference known-answer vectors ---------------------------------------------------------
+@pytest.mark.parametrize("key", ["fmult2x2_pow2", "fmult2x2_nopow2"])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_poly_fmult2x2_golden(capi, fixtures, key, normalize):
+    fx = fixtures[key]
+    exact = S.l2c(fx["result_exact"])
+    p = S.fmult_test_input(fx["deg"], fx["n"])
+    rc, d, res, W = capi.poly_fmult2x2(fx["deg"], fx["n"], p, normalize=normalize)
+    assert rc == 0, capi.last_error()
+    assert d == exact.size // 4 - 1
+    if normalize:
+        assert W != 0
+        res = res * 2.0 ** W
+    assert S.rel_err(res.ravel(), exact) <= fx["tol_rel_l1"]
+
+
+def test_poly_chirpz_golden(capi, fixtures):
+    fx = fixtures["chirpz"]
+    p = S.l2c(fx["p"])
+    for M, key in ((3, "result_M3"), (6, "result_M6")):
+        rc, out = capi.poly_chirpz(p, complex(*fx["A"]), np.exp(1j * fx["W_arg"]), M)
+        assert rc == 0, capi.last_error()
+        assert S.rel_err(out, S.l2c(fx[key])) <= fx["tol_rel_l1"]
+
+
+@pytest.mark.parametrize("scheme", AKNS_SCHEMES)
+@pytest.mark.parametrize("normalize", [False, True])
+def test_akns_fscatter_golden(capi, oracle, fixtures, scheme, normalize):
+    fx = fixtures["akns_fscatter"]["schemes"][scheme]
+    q, r, z = S.akns_test_signal(fx["D"])
+    rc, deg, tm, W = capi.akns_fscatter(q, r, fx["eps_t"], scheme, normalize=normalize)
+    assert rc == 0, capi.last_error()
+    if normalize:
+        assert W != 0
+        tm = tm * 2.0 ** W
+    vals = np.concatenate([oracle.poly_eval(tm[e], z) for e in range(4)])
+    assert S.rel_err(vals, S.l2c(fx["result_exact"])) <= fixtures["akns_fscatter"]["tol_rel_l1"]
+
+
+# ---- product tree vs oracle on seeded inputs ----------------------------------------------------
+@pytest.mark.parametrize("deg,n", [(1, 1), (1, 2), (1, 3), (1, 7), (2, 8), (2, 13), (3, 6), (4, 5),
+                                   (5, 9), (7, 33), (1, 64), (2, 100), (3, 300), (1, 1000)])
+def test_poly_fmult2x2_vs_oracle(capi, oracle, deg, n):
+    rng = np.random.default_rng(1000 * deg + n)
+    p = 0.3 * (rng.standard_normal((4, n * (deg + 1))) + 1j * rng.standard_normal((4, n * (deg + 1))))
+    rc, d, res, W = capi.poly_fmult2x2(deg, n, p)
+    assert rc == 0, capi.last_error()
+    d2, ref, W2 = oracle.poly_fmult2x2(deg, n, p)
+    assert d == d2 == deg * n
+    a = res.astype(np.clongdouble) * np.ldexp(np.longdouble(1), W)
+    b = ref.astype(np.clongdouble) * np.ldexp(np.longdouble(1), W2)
+    assert float(np.sum(np.abs(a - b)) / np.sum(np.abs(b))) < 1e-12
+
+
+def _tm_err(capi_tm, W, ref_tm, W2):
+    a = capi_tm.astype(np.clongdouble) * np.ldexp(np.longdouble(1), W)
+    b = ref_tm.astype(np.clongdouble) * np.ldexp(np.longdouble(1), W2)
+    return float(np.sum(np.abs(a - b)) / np.sum(np.abs(b)))
+
+
+@pytest.mark.parametrize("D,disc", [(2, "2SPLIT2_MODAL"), (3, "2SPLIT4B"), (255, "2SPLIT2_MODAL"),
+                                    (4096, "2SPLIT2_MODAL"), (4097, "2SPLIT4B"), (8192, "2SPLIT4B"),
+                                    (16384, "2SPLIT2_MODAL"), (3000, "2SPLIT3A"), (5000, "2SPLIT4A"),
+                                    (65536, "2SPLIT2_MODAL"), (65536, "2SPLIT4B")])
+@pytest.mark.parametrize("kappa", [1, -1])
+def test_nse_fscatter_vs_oracle(capi, oracle, D, disc, kappa):
+    """Transfer matrices (coeffs * 2^W) of sech pulses; covers fused levels and split transforms."""
+    T = (-25.0, 25.0)
+    q = S.sech_focusing(D, T, amp=1.4 if kappa == -1 else 3.2) * np.exp(0.3j * S.tgrid(T, D))
+    eps_t = (T[1] - T[0]) / (D - 1)
+    rc, deg, tm, W = capi.nse_fscatter(q, eps_t, kappa, disc)
+    assert rc == 0, capi.last_error()
+    rc2, deg2, ref, W2 = oracle.nse_fscatter(q, eps_t, kappa, disc)
+    assert rc2 == 0 and deg == deg2
+    # error normalised by the largest coefficient: small coefficients of an FFT
+    # product carry absolute, not relative, accuracy in the reference as well
+    a = tm.astype(np.clongdouble) * np.ldexp(np.longdouble(1), W)
+    b = ref.astype(np.clongdouble) * np.ldexp(np.longdouble(1), W2)
+    assert float(np.max(np.abs(a - b)) / np.max(np.abs(b))) < tol_for(D)
+
+
+# ---- full transform vs oracle ---------------------------------------------------------------------
+@pytest.mark.parametrize("D,M,disc", [
+    (2, 2, "2SPLIT2_MODAL"), (256, 16, "2SPLIT2_MODAL"), (256, 64, "2SPLIT4B"), (1000, 37, "2SPLIT2A"),
+    (4096, 16, "2SPLIT2_MODAL"), (4096, 4096, "2SPLIT2_MODAL"), (4097, 100, "2SPLIT4B"),
+    (4095, 4095, "2SPLIT4B"), (300, 50, "2SPLIT3A"), (512, 33, "2SPLIT4A"), (777, 40, "2SPLIT1A"),
+    (640, 64, "2SPLIT1B"), (2048, 128, "2SPLIT2B"), (2048, 128, "2SPLIT2S"), (1500, 64, "2SPLIT3B"),
+    (1500, 64, "2SPLIT3S"), (16384, 16384, "2SPLIT2_MODAL"), (65536, 65536, "2SPLIT2_MODAL"),
+    (65536, 1000, "2SPLIT4B"),
+])
+def test_fnft_nsev_vs_oracle(capi, oracle, D, M, disc):
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    q = S.sech_focusing(D)
+    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, discretization=disc, contspec_type="BOTH")
+    assert rc == 0, capi.last_error()
+    rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc=disc, cstype="BOTH")
+    assert rc2 == 0
+    tol = tol_for(D)
+    assert S.rel_err(cs[:M], ref[:M]) < tol
+    assert S.rel_err(cs[M:2 * M], ref[M:2 * M]) < tol
+    assert S.rel_err(cs[2 * M:], ref[2 * M:]) < tol
+
+
+@pytest.mark.parametrize("cstype", ["RHO", "AB", "BOTH"])
+@pytest.mark.parametrize("norm", [0, 1])
+def test_cstype_and_normalization(capi, oracle, cstype, norm):
+    D, M = 1024, 200
+    T, XI = [-20.0, 22.0], [-3.0, 2.5]
+    q = S.batch_signal(3, D, T)
+    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type=cstype,
+                            normalization_flag=norm)
+    assert rc == 0, capi.last_error()
+    rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc="2SPLIT4B", cstype=cstype, normalize=bool(norm))
+    assert rc2 == 0 and cs.size == ref.size
+    assert S.rel_err(cs, ref) < 1e-12
+
+
+def test_defocusing(capi, oracle, fixtures):
+    fx = fixtures["nsev_sech_defocusing"]
+    D, M = 4096, fx["M"]
+    q = S.sech_defocusing(D)
+    for disc, bound in (("2SPLIT2_MODAL", 1.2e-4), ("2SPLIT4B", 1.3e-4)):
+        rc, cs = capi.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=-1, discretization=disc,
+                                contspec_type="REFLECTION_COEFFICIENT")
+        assert rc == 0, capi.last_error()
+        assert S.rel_err(cs, S.l2c(fx["contspec"])) <= bound  # test/fnft_nsev/..._defocusing_*.c
+        rc2, ref = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=-1, disc=disc, cstype="RHO")
+        assert S.rel_err(cs, ref) < 1e-12
+
+
+# ---- the reference's analytic integration tests, run on the GPU path ---------------------------
+def _analytic_cases():
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_fixtures.json")) as f:
+        fx = json.load(f)
+    out = []
+    for b in fx["nsev_error_bounds"]:
+        if b["discretization"] in AKNS_SCHEMES and b["testcase"] == "SECH_FOCUSING" \
+                and np.isfinite(b["error_bounds"][0]):
+            out.append(pytest.param(b, id=b["discretization"]))
+    return out
+
+
+@pytest.mark.parametrize("b", _analytic_cases())
+def test_fnft_nsev_analytic_bounds(capi, fixtures, b):
+    """src/private/fnft__nsev_testcases.c:711-822 at D, D+1, D-1, 2D with the test's own bounds."""
+    fx = fixtures["nsev_sech_focusing"]
+    M = fx["M"]
+    stages = [(b["D"], b["error_bounds"]), (b["D"] + 1, b["error_bounds"]), (b["D"] - 1, b["error_bounds"])]
+    if b.get("error_bounds_2D"):
+        stages.append((2 * b["D"], b["error_bounds_2D"]))
+    exact_rho, exact_ab = S.l2c(fx["contspec"]), S.l2c(fx["ab"])
+    for D, bounds in stages:
+        rc, cs = capi.fnft_nsev(S.sech_focusing(D), fx["T"], M, fx["XI"], kappa=1,
+                                discretization=b["discretization"], contspec_type="BOTH")
+        assert rc == 0, capi.last_error()
+        errs = [S.rel_err(cs[:M], exact_rho), S.rel_err(cs[M:2 * M], exact_ab[:M]),
+                S.rel_err(cs[2 * M:], exact_ab[M:])]
+        for e, bound in zip(errs, bounds):
+            assert e <= bound, (D, errs, bounds)
+
+
+# ---- BASELINE.json full size: properties that do not need a CPU run of that size ---------------
+@pytest.mark.parametrize("disc,order_bound", [("2SPLIT2_MODAL", 5.0e-3), ("2SPLIT4B", 3.9e-6)])
+def test_full_size_2p20_analytic(capi, disc, order_bound):
+    """cfg 2: D = M = 2^20.  Every grid point is compared with the closed-form Satsuma-Yajima
+    spectrum; the discretization error of a second-order scheme falls as (4096/D)^2 from the
+    reference's own bound at D = 4096 (test/fnft_nsev/fnft_nsev_test_sech_focusing_*.c)."""
+    D = M = 1 << 20
+    T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
+    q = S.sech_focusing(D)
+    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, discretization=disc, contspec_type="BOTH")
+    assert rc == 0, capi.last_error()
+    xi = XI[0] + np.arange(M) * (XI[1] - XI[0]) / (M - 1)
+    a, b = S.sech_focusing_analytic(xi)
+    bound = max(order_bound * (4096.0 / D) ** 2 * 4.0, 2e-9)
+    assert S.rel_err(cs[M:2 * M], a) < bound
+    assert S.rel_err(cs[2 * M:], b) < bound
+    assert S.rel_err(cs[:M], b / a) < bound
+    # |a|^2 + |b|^2 = 1 on the real axis for the focusing NSE (unimodularity of the transfer
+    # matrix): a size-independent invariant of the whole pipeline
+    inv = np.abs(cs[M:2 * M]) ** 2 + np.abs(cs[2 * M:]) ** 2
+    assert np.max(np.abs(inv - 1.0)) < 1e-7
+
+
+def test_full_size_2p20_vs_oracle(capi, oracle):
+    """cfg 2 against the CPU oracle at the full size (about 15 s of CPU): MODAL, a, b and rho."""
+    D = M = 1 << 20
+    T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
+    q = S.sech_focusing(D)
+    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT2_MODAL", contspec_type="BOTH")
+    assert rc == 0, capi.last_error()
+    rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc="2SPLIT2_MODAL", cstype="BOTH")
+    assert rc2 == 0
+    tol = tol_for(D)
+    for k in range(3):
+        assert S.rel_err(cs[k * M:(k + 1) * M], ref[k * M:(k + 1) * M]) < tol
+
+
+# ---- device-resident batch API -------------------------------------------------------------------
+def test_batch_plan_device(capi, oracle):
+    import torch
+    D, M, B = 4096, 512, 6
+    T, XI = [-25.0, 25.0], [-4.0, 4.0]
+    qs = np.stack([S.batch_signal(k, D, T) for k in range(B)])
+    plan = capi.Plan(D, M, batch=B, discretization="2SPLIT2_MODAL")
+    dq = torch.from_numpy(qs).cuda()
+    out = torch.zeros(B * 3 * M, dtype=torch.complex128, device="cuda")
+    torch.cuda.synchronize()
+    rc = plan.contspec_device(dq.data_ptr(), out.data_ptr(), T, XI, kappa=1, contspec_type="BOTH")
+    assert rc == 0, capi.last_error()
+    assert plan.finish() == 0
+    res = out.cpu().numpy().reshape(B, 3 * M)
+    for k in range(B):
+        rc2, ref = oracle.fnft_nsev(qs[k], T, M, XI, kappa=1, disc="2SPLIT2_MODAL", cstype="BOTH")
+        assert rc2 == 0
+        assert S.rel_err(res[k], ref) < 1e-12, k
+    rc, deg, tm, W = plan.transfer_matrix(2)
+    eps_t = (T[1] - T[0]) / (D - 1)
+    rc2, deg2, ref_tm, W2 = oracle.nse_fscatter(qs[2], eps_t, 1, "2SPLIT2_MODAL")
+    assert rc == 0 and deg == deg2
+    assert _tm_err(tm, W, ref_tm, W2) < 1e-10
+    plan.close()
+
+
+# ---- error behaviour that needs the device ----------------------------------------------------------
+def test_modal_step_size_error(capi):
+    """fnft__akns_fscatter.c:122-126 -> fnft_nsev returns -5 (E_OTHER wrapped by CHECK_RETCODE)."""
+    capi.silence_errors()
+    q = np.full(16, 40.0 + 0j)
+    rc, _ = capi.fnft_nsev(q, [0.0, 1.0], 8, [-1.0, 1.0], kappa=-1, discretization="2SPLIT2_MODAL")
+    assert rc == -5
