@@ -77,6 +77,13 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch wheels bundle their own copy of the HIP/HSA runtime.  Two copies in one process
+    # cannot both own the GPU, so when torch is installed it is imported FIRST: the loader then
+    # resolves this library's libamdhip64.so.7 to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(p):
         raise RuntimeError(
             "libfnft_amd.so not found at %s -- run `python -m fnft_amd.build` (hipcc, gfx950); "

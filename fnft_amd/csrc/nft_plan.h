@@ -69,6 +69,20 @@ inline int nft_nse_to_akns(int nse_disc)
     }
 }
 
+// log of a complex number through libm's clog -- the routine glibc's cpow() (which the reference
+// calls for every chirp factor, src/private/fnft__poly_chirpz.c:69,77,81,95) is built on.  It keeps
+// the tiny real part log|z| of a z that is on the unit circle only up to rounding; the generic
+// std::log(std::complex) of some C++ runtimes returns log(hypot) = 0 there, which changes
+// |z|^(n^2/2) by up to 1e-9 at n = 2^16.
+inline std::complex<double> nft_clog(std::complex<double> z)
+{
+    __complex__ double zz;
+    __real__ zz = z.real();
+    __imag__ zz = z.imag();
+    const __complex__ double r = __builtin_clog(zz);
+    return std::complex<double>(__real__ r, __imag__ r);
+}
+
 // transform length used for a product of two degree-d polynomials
 inline size_t nft_product_len(size_t d)
 {
@@ -147,7 +161,20 @@ public:
             ok = ok && alloc(body[i], 4 * plane) && alloc(tail[i], 4 * n0) && alloc(scale[i], n0);
         }
         ok = ok && alloc(max2, n0) && alloc(W, batch) && alloc(status, 4);
-        if (topN > (size_t)kFusedMaxN) ok = ok && alloc(Y, 8 * plane) && alloc(Z, 4 * plane);
+        {   // scratch of the split transforms: 4*n_in polynomials of N forward, 4*n_out inverse,
+            // maximised over the levels that use them (N can exceed 2d when d is not 2^k)
+            size_t needY = 0, needZ = 0, n = n0, d = (size_t)deg0;
+            while (n / batch > 1) {
+                const size_t N = nft_product_len(d);
+                if (d > (size_t)kSchoolMaxDeg && N > (size_t)kFusedMaxN) {
+                    if (4 * n * N > needY) needY = 4 * n * N;
+                    if (2 * n * N > needZ) needZ = 2 * n * N;
+                }
+                n /= 2;
+                d *= 2;
+            }
+            if (needY) ok = ok && alloc(Y, needY) && alloc(Z, needZ);
+        }
         if (M > 0) {
             const size_t Np = D * (size_t)deg0 + 1;
             Lc = nft_nextpow2(Np + M - 1);
@@ -334,7 +361,7 @@ public:
         const double phiA = 2.0 * (-cs.XI[0]) * eps_t / deg1;
         const std::complex<double> V(std::cos(phiV), std::sin(phiV));
         const std::complex<double> A(std::cos(phiA), std::sin(phiA));
-        const std::complex<double> lV = std::log(V), lA = std::log(A);
+        const std::complex<double> lV = nft_clog(V), lA = nft_clog(A);
 
         ChirpParams C;
         std::memset(&C, 0, sizeof(C));
@@ -397,7 +424,7 @@ public:
             pl.upload_twiddles();
             be.h2d(dp, p, (deg + 1) * sizeof(cplx));
             be.memset0(dstatus, 4 * sizeof(int));
-            const std::complex<double> lA = std::log(A), lW = std::log(Wc);
+            const std::complex<double> lA = nft_clog(A), lW = nft_clog(Wc);
             ChirpParams C;
             std::memset(&C, 0, sizeof(C));
             C.poly = dp;

@@ -15,8 +15,6 @@
 #include <string.h>
 #include <time.h>
 
-static const double ORC_PI = 3.14159265358979323846264338327950288;
-
 static double now_s(void)
 {
     struct timespec ts;
@@ -69,10 +67,13 @@ static int plan_init(orc_plan *pl, size_t len, int sign)
     pl->tw = malloc(len * sizeof(orc_cplx));
     pl->work = malloc(len * sizeof(orc_cplx));
     if (!pl->tw || !pl->work) return ORC_EC_NOMEM;
+    /* Table in extended precision, rounded once.  (KissFFT forms cos/sin of a double-rounded
+     * angle, kiss_fft.c:357-363; the rounding of the angle is a bias common to every transform of
+     * the tree and accumulates linearly in the number of products -- the checker avoids it.) */
+    const long double tau = 6.283185307179586476925286766559005768L;
     for (size_t k = 0; k < len; k++) {
-        /* reduce the angle through the exact octant symmetries for accuracy */
-        double ang = (double)sign * 2.0 * ORC_PI * (double)k / (double)len;
-        pl->tw[k] = cos(ang) + I * sin(ang);
+        const long double ang = (long double)sign * tau * (long double)k / (long double)len;
+        pl->tw[k] = (double)cosl(ang) + I * (double)sinl(ang);
     }
     return ORC_SUCCESS;
 }
@@ -230,14 +231,14 @@ static void pair_product(size_t deg, const orc_cplx *a11, size_t a_stride, const
     const orc_cplx *A11 = spec, *A12 = spec + len, *A21 = spec + 2 * len, *A22 = spec + 3 * len;
     const orc_cplx *B11 = spec + 4 * len, *B12 = spec + 5 * len, *B21 = spec + 6 * len,
                    *B22 = spec + 7 * len;
-    const double scl = 1.0 / (double)len;
+    const double dlen = (double)len; /* divide (fnft__poly_fmult.c:110-111): 1/len is not exact */
     for (int e = 0; e < 4; e++) {
         const orc_cplx *L1 = (e < 2) ? A11 : A21, *L2 = (e < 2) ? A12 : A22;
         const orc_cplx *R1 = (e % 2 == 0) ? B11 : B12, *R2 = (e % 2 == 0) ? B21 : B22;
         for (size_t k = 0; k < len; k++) tmp[k] = L1[k] * R1[k] + L2[k] * R2[k];
         plan_exec(inv, tmp, tmp + len);
         orc_cplx *dst = c11 + (size_t)e * c_stride;
-        for (size_t k = 0; k < 2 * deg + 1; k++) dst[k] = tmp[len + k] * scl;
+        for (size_t k = 0; k < 2 * deg + 1; k++) dst[k] = tmp[len + k] / dlen;
     }
 }
 

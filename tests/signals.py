@@ -117,6 +117,7 @@ def poly_matmul_direct(P, Q):
 def tree_direct(p, deg, n):
     """Ordered product P_0 P_1 ... P_{n-1} by direct convolution in long double-free numpy
     (balanced tree like the reference).  p: [4, n*(deg+1)]."""
+    p = np.asarray(p)
     mats = [p[:, j * (deg + 1):(j + 1) * (deg + 1)] for j in range(n)]
     while len(mats) > 1:
         nxt = []
