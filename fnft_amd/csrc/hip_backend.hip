@@ -242,7 +242,7 @@ FNFT_INT fnft_amd_plan_get_transfer_matrix(fnft_amd_plan_t *plan, FNFT_UINT b,
     const size_t per = 4 * (pl.res_deg + 1);
     plan->be.d2h(result_host, pl.tm_out + b * per, per * sizeof(cplx));
     int w = 0;
-    plan->be.d2h(&w, pl.W + b, sizeof(int));
+    plan->be.d2h(&w, pl.wexp[pl.cur] + b, sizeof(int));
     const int rc = plan->be.sync();
     if (deg) *deg = pl.res_deg;
     if (W) *W = w;

@@ -21,7 +21,7 @@ int api_poly_fmult2x2(BE &be, size_t *d, size_t n, std::complex<double> *p,
         const size_t cnt = 4 * (pl.res_deg + 1);
         be.d2h(result, pl.tm_out, cnt * sizeof(cplx));
         int W = 0;
-        be.d2h(&W, pl.W, sizeof(int));
+        be.d2h(&W, pl.wexp[pl.cur], sizeof(int));
         rc = be.sync();
         if (rc == NFT_SUCCESS) {
             *d = pl.res_deg;
@@ -62,7 +62,7 @@ int api_akns_fscatter(BE &be, size_t D, const std::complex<double> *q, const std
         const size_t cnt = 4 * (pl.res_deg + 1);
         be.d2h(result, pl.tm_out, cnt * sizeof(cplx));
         int W = 0;
-        be.d2h(&W, pl.W, sizeof(int));
+        be.d2h(&W, pl.wexp[pl.cur], sizeof(int));
         rc = pl.read_status();
         if (rc == -NFT_EC_OTHER) rc = NFT_EC_OTHER;  // raised by akns_fscatter itself
         if (rc == NFT_SUCCESS) {

@@ -17,6 +17,15 @@ template <int DEG> struct KCoeffs {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_coeffs<DEG>(p); }
 };
+template <int DEG> struct LeafCfg {
+    static constexpr int SPT = (DEG == 1) ? 8 : (DEG == 2 ? 4 : 2);
+};
+template <int DEG> struct KLeaf {
+    using Params = LeafParams;
+    static constexpr int THREADS = 128;
+    static constexpr size_t lds_bytes() { return (size_t)THREADS * DEG * LeafCfg<DEG>::SPT * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_leaf<DEG, LeafCfg<DEG>::SPT>(p); }
+};
 template <int DEG> struct KPairSchool {
     using Params = TreeLevel;
     static constexpr int THREADS = 128;
@@ -51,7 +60,7 @@ template <int N> struct KPairFft {
     static constexpr int MIN_WAVES = (C::THREADS > 256) ? 2 : 1;
     static constexpr size_t lds_bytes()
     {
-        return (N > C::R ? (size_t)2 * N * C::B * sizeof(cplx) : 0) + (size_t)C::B * 8;
+        return (N > C::R ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx) + (size_t)C::B * 8;
     }
     static FA_DEV void body(const Params &p) { body_pair_fft<N, C::R, C::B>(p); }
 };
@@ -123,6 +132,30 @@ template <class BE> bool dispatch_coeffs(BE &be, const CoeffParams &p)
     case 2: be.template run<KCoeffs<2>>(g, 1, p); return true;
     case 3: be.template run<KCoeffs<3>>(g, 1, p); return true;
     case 4: be.template run<KCoeffs<4>>(g, 1, p); return true;
+    default: return false;
+    }
+}
+
+// samples per lane of the leaf kernel for this degree (0: no leaf kernel)
+inline int leaf_spt(int deg)
+{
+    switch (deg) {
+    case 1: return LeafCfg<1>::SPT;
+    case 2: return LeafCfg<2>::SPT;
+    case 3: return LeafCfg<3>::SPT;
+    case 4: return LeafCfg<4>::SPT;
+    default: return 0;
+    }
+}
+template <class BE> bool dispatch_leaf(BE &be, const LeafParams &p)
+{
+    const long long n = (long long)p.c.batch * (p.c.Dpad / p.spt);
+    const int g = (int)((n + 127) / 128);
+    switch (p.c.deg) {
+    case 1: be.template run<KLeaf<1>>(g, 1, p); return true;
+    case 2: be.template run<KLeaf<2>>(g, 1, p); return true;
+    case 3: be.template run<KLeaf<3>>(g, 1, p); return true;
+    case 4: be.template run<KLeaf<4>>(g, 1, p); return true;
     default: return false;
     }
 }

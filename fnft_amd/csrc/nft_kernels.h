@@ -16,8 +16,10 @@
 // the odd "+1" coefficient out of the body makes every body a power-of-two run of 16-byte
 // elements and lets a product of two degree-d matrices use a cyclic transform of length 2d: the
 // only aliased coefficient, index 2d, is the product of the two constant terms and is formed
-// directly.  scale[j] is a pending power of two (true matrix = stored * scale[j]); W[signal]
-// accumulates the exponents taken out, true product = stored * 2^W (fnft__poly_fmult.c:493).
+// directly.  scale[j] is a pending power of two (true matrix = stored * scale[j])
+// and wexp[j]
+// carries the exponents taken out of everything below matrix j (summed up the tree without
+// atomics), so that at the root true product = stored * 2^W (fnft__poly_fmult.c:493).
 #pragma once
 #include "fft_dev.h"
 
@@ -32,7 +34,8 @@ struct TreeLevel {
     cplx *tail_out;
     double *scale_out;
     unsigned long long *max2_out;  // per output matrix: bits of max |coef|^2 (large path)
-    int *W;                        // per signal
+    const int *wexp_in;            // per input matrix: power-of-two exponent taken out so far
+    int *wexp_out;                 // per output matrix: wexp_in[2P] + wexp_in[2P+1] + this level's
     size_t plane;                  // body plane stride, elements
     int n_in;                      // matrices entering this level (all signals)
     int d;                         // their degree
@@ -133,6 +136,7 @@ struct CoeffParams {
     cplx *body;          // 4 planes
     cplx *tail;          // 4 planes of n = batch*Dpad
     double *scale;       // n
+    int *wexp;           // n: exponent taken out (0 at level 0, set by the leaf kernel)
     int *status;         // bit 0: MODAL step-size check failed
     size_t plane;
     double eps_t;
@@ -277,6 +281,138 @@ template <int DEG> FA_DEV void body_coeffs(const CoeffParams &P)
         P.tail[(size_t)e * n + gid] = m.p[e][DEG];
     }
     P.scale[gid] = 1.0;
+    P.wexp[gid] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1+: leaf kernel = coefficients of SPT consecutive samples AND their ordered product, all in
+// registers of one lane (levels 0 .. log2(SPT)-1 of the tree never touch HBM).  Replaces the
+// reference's coefficient loop plus the first log2(SPT) rounds of fnft__poly_fmult.c:460-519.
+// Output: matrices of degree DEG*SPT in the body/tail layout, already rescaled (scale = 1).
+// ---------------------------------------------------------------------------------------------
+struct LeafParams {
+    CoeffParams c;       // q, r, eps_t, ... ; body/tail/scale/wexp are the OUTPUT level
+    int spt;
+};
+
+template <int DEG, int SPT, int S> struct LeafStep {
+    // acc (degree DEG*S) <- acc * u (degree DEG)
+    static FA_DEV void mul(cplx (&acc)[4][DEG * SPT + 1], const CoefMat<DEG> &u)
+    {
+        constexpr int DC = DEG * S;
+#pragma unroll
+        for (int row = 0; row < 2; row++) {
+            cplx a0[DC + 1], a1[DC + 1];
+#pragma unroll
+            for (int i = 0; i <= DC; i++) {
+                a0[i] = acc[2 * row][i];
+                a1[i] = acc[2 * row + 1][i];
+            }
+#pragma unroll
+            for (int col = 0; col < 2; col++) {
+                cplx r[DC + DEG + 1];
+#pragma unroll
+                for (int k = 0; k <= DC + DEG; k++) r[k] = cmake(0.0, 0.0);
+#pragma unroll
+                for (int i = 0; i <= DC; i++)
+#pragma unroll
+                    for (int j = 0; j <= DEG; j++) {
+                        r[i + j] = cfma(a0[i], u.p[col][j], r[i + j]);
+                        r[i + j] = cfma(a1[i], u.p[2 + col][j], r[i + j]);
+                    }
+#pragma unroll
+                for (int k = 0; k <= DC + DEG; k++) acc[2 * row + col][k] = r[k];
+            }
+        }
+    }
+};
+
+template <int DEG> FA_DEV bool leaf_sample(const CoeffParams &P, int b, long long j, CoefMat<DEG> &m)
+{
+    if (j < P.D) {
+        const size_t src = (size_t)b * P.D + (size_t)(P.D - 1 - j);
+        const cplx q = P.q[src];
+        const cplx r = P.r ? P.r[src] : (P.kappa == 1 ? cmake(-q.x, q.y) : cmake(q.x, -q.y));
+        return sample_coeffs<DEG>(P.disc, P.eps_t, q, r, m);
+    }
+    coeffs_zero(m);
+    m.p[0][0] = cmake(1.0, 0.0);
+    m.p[3][0] = cmake(1.0, 0.0);
+    return true;
+}
+
+template <int DEG, int SPT, int S> struct LeafLoop {
+    static FA_DEV void run(const CoeffParams &P, int b, long long j0, cplx (&acc)[4][DEG * SPT + 1], bool &ok)
+    {
+        if constexpr (S < SPT) {
+            CoefMat<DEG> u;
+            ok = leaf_sample<DEG>(P, b, j0 + S, u) && ok;
+            LeafStep<DEG, SPT, S>::mul(acc, u);
+            LeafLoop<DEG, SPT, S + 1>::run(P, b, j0, acc, ok);
+        }
+    }
+};
+
+template <int DEG, int SPT> FA_DEV void body_leaf(const LeafParams &LP)
+{
+    FA_LDS_DECL
+    cplx *stage = (cplx *)FA_LDS_PTR;  // FA_BDIM * d elements
+    const CoeffParams &P = LP.c;
+    const int tid = FA_TID;
+    const long long g0 = (long long)FA_BID * FA_BDIM;
+    const long long gid = g0 + tid;
+    const long long per = P.Dpad / SPT;            // output matrices per signal
+    const long long n_out = (long long)P.batch * per;
+    const bool active = gid < n_out;
+    const int b = active ? (int)(gid / per) : 0;
+    const long long j0 = active ? (gid % per) * SPT : 0;
+    constexpr int d = DEG * SPT;
+    cplx acc[4][d + 1];
+    bool ok = true;
+    double sc = 1.0;
+    if (active) {
+        {
+            CoefMat<DEG> m;
+            ok = leaf_sample<DEG>(P, b, j0, m);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int k = 0; k <= DEG; k++) acc[e][k] = m.p[e][k];
+            }
+        }
+        LeafLoop<DEG, SPT, 1>::run(P, b, j0, acc, ok);
+        if (!ok) fa_atomic_or_i32(P.status, 1);
+        double m2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int k = 0; k <= d; k++) m2 = fmax(m2, cnorm2(acc[e][k]));
+        int a = 0;
+        if (m2 > 0.0 && m2 < 1.0e300) {
+            a = half_exponent(m2);
+            sc = pow2i(-a);
+        }
+        P.scale[gid] = 1.0;
+        P.wexp[gid] = a;
+    }
+    // bodies leave through LDS so that lanes write consecutive 16-byte elements (full lines)
+    const long long nvalid = (n_out - g0 < FA_BDIM) ? n_out - g0 : FA_BDIM;
+    const int total = (int)nvalid * d;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < d; k++) stage[(size_t)tid * d + ((k + tid) % d)] = acc[e][k] * sc;
+            P.tail[(size_t)e * n_out + gid] = acc[e][d] * sc;
+        }
+        FA_SYNC();
+        cplx *out0 = P.body + (size_t)e * P.plane + (size_t)g0 * d;
+        for (int m = tid; m < total; m += FA_BDIM) {
+            const int t2 = m / d, k2 = m - t2 * d;
+            out0[m] = stage[(size_t)t2 * d + ((k2 + t2) % d)];
+        }
+        FA_SYNC();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,7 +469,7 @@ template <int DEG> FA_DEV void body_pair_school(const TreeLevel &L)
         L.tail_out[(size_t)e * n_out + P] = C[e][2 * d] * sc;
     }
     L.scale_out[P] = 1.0;
-    if (a != 0) fa_atomic_add_i32(&L.W[P / L.pairs_per_signal], a);
+    L.wexp_out[P] = L.wexp_in[2 * P] + L.wexp_in[2 * P + 1] + a;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -369,9 +505,9 @@ template <int N, int R, int B, class IO> FA_DEV void pair_product_core(IO &io, c
             b2[i] = cfma(a[3][i], x2, a[2][i] * x1);
         }
         fft_wg<N, R, B, +1>(b1, lds, v, c, tw, parity);
-        io.store(col, b1, v, c);
+        io.store(col, b1, v, c, lds, parity);
         fft_wg<N, R, B, +1>(b2, lds, v, c, tw, parity);
-        io.store(2 + col, b2, v, c);
+        io.store(2 + col, b2, v, c, lds, parity);
     }
 }
 
@@ -415,36 +551,64 @@ template <int N, int R, int B> struct TreeIO {
         const int row = e >> 1, col = e & 1;
         return cfma(tail(0, 2 * row + 1), tail(1, 2 + col), tail(0, 2 * row) * tail(1, col));
     }
-    FA_DEV void store(int e, cplx (&x)[R], int v, int)
+    // Results leave through LDS when a workgroup holds several pairs (B > 1): lane (v, c) owns a
+    // strided sliver of pair c, and 16-byte stores at a 2d*16-byte lane stride reach HBM as
+    // partial lines (measured 5x-20x slower than full lines).  The idle transform buffer
+    // lds[parity] is the staging area (rows rotated by c against bank conflicts); flipping the
+    // parity afterwards keeps the one-barrier-per-exchange hand-over of fft_wg valid.
+    FA_DEV void store(int e, cplx (&x)[R], int v, int c, cplx *lds, int &parity)
     {
-        if (!active) return;
         const int d2 = 2 * L.d;
-        cplx *dst = L.body_out + (size_t)e * L.plane + (size_t)P * d2;
+        const int n_out = L.n_in / 2;
         const double inv = 1.0 / (double)N;
+        cplx *stage = lds + ((N > R) ? (size_t)parity * (size_t)(N * B) : 0);
+        cplx *dst = L.body_out + (size_t)e * L.plane + (size_t)P * d2;
+        if (B > 1 && N == R) FA_SYNC();  // no transform barrier separates consecutive stores
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const int idx = v + (N / R) * i;
             cplx val = x[i] * inv;
-            if (idx == 0) {
+            if (active && idx == 0) {
                 const cplx tp = tail_product(e);
                 if (N == d2) val = val - tp;  // un-alias coefficient 2d folded onto 0
-                L.tail_out[(size_t)e * (L.n_in / 2) + P] = tp;
+                L.tail_out[(size_t)e * n_out + P] = tp;
                 m2 = fmax(m2, cnorm2(tp));
             }
-            if (idx < d2) {
-                dst[idx] = val;
+            if (active && idx < d2) {
                 m2 = fmax(m2, cnorm2(val));
+                if (B > 1) {
+                    int rot = idx + c;
+                    rot = rot >= d2 ? rot - d2 * (rot / d2) : rot;
+                    stage[(size_t)c * d2 + rot] = val;
+                } else {
+                    dst[idx] = val;
+                }
             }
+        }
+        if (B > 1) {
+            FA_SYNC();
+            const long long P0 = (long long)FA_BID * B;
+            const long long nvalid = (n_out - P0 < B) ? n_out - P0 : B;
+            const int total = (int)nvalid * d2;
+            cplx *out0 = L.body_out + (size_t)e * L.plane + (size_t)P0 * d2;
+            for (int m = FA_TID; m < total; m += B * (N / R)) {
+                const int c2 = m / d2, i2 = m - c2 * d2;
+                int rot = i2 + c2;
+                rot = rot >= d2 ? rot - d2 * (rot / d2) : rot;
+                out0[m] = stage[(size_t)c2 * d2 + rot];
+            }
+            if (N > R) parity ^= 1;
         }
     }
 };
 
-// LDS: 2*N*B transform buffers (none when N == R), then B u64 slots for the per-pair maxima.
+// LDS: 2*N*B transform buffers (N > R) or one N*B staging buffer (N == R), then B u64 slots for
+// the per-pair maxima.
 template <int N, int R, int B> FA_DEV void body_pair_fft(const TreeLevel &L)
 {
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
-    unsigned long long *mx = (unsigned long long *)(lds + (N > R ? (size_t)2 * N * B : 0));
+    unsigned long long *mx = (unsigned long long *)(lds + (N > R ? (size_t)2 * N * B : (size_t)N * B));
     const int tid = FA_TID;
     const int c = tid % B, v = tid / B;
     if (v == 0) mx[c] = 0ull;
@@ -463,7 +627,7 @@ template <int N, int R, int B> FA_DEV void body_pair_fft(const TreeLevel &L)
         int a = 0;
         if (m2 > 0.0 && m2 < 1.0e300) a = half_exponent(m2);
         L.scale_out[io.P] = pow2i(-a);
-        if (a != 0) fa_atomic_add_i32(&L.W[io.P / L.pairs_per_signal], a);
+        L.wexp_out[io.P] = L.wexp_in[2 * io.P] + L.wexp_in[2 * io.P + 1] + a;
     }
 }
 
@@ -536,7 +700,7 @@ template <int N2, int R> struct MidIO {
 #pragma unroll
         for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i];
     }
-    FA_DEV void store(int e, cplx (&x)[R], int v, int)
+    FA_DEV void store(int e, cplx (&x)[R], int v, int, cplx *, int &)
     {
         const int n_out = G.L.n_in / 2;
         cplx *dst = G.Z + ((size_t)((size_t)e * n_out + P) * G.N1 + k1) * N2;
@@ -619,7 +783,7 @@ FA_DEV void body_finalize_scales(const TreeLevel &L)
     if (m2 > 0.0 && m2 < 1.0e300) a = half_exponent(m2);
     L.scale_out[P] = pow2i(-a);
     L.max2_out[P] = 0ull;
-    if (a != 0) fa_atomic_add_i32(&L.W[P / L.pairs_per_signal], a);
+    L.wexp_out[P] = L.wexp_in[2 * P] + L.wexp_in[2 * P + 1] + a;
 }
 
 // ---------------------------------------------------------------------------------------------

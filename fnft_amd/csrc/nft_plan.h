@@ -106,7 +106,7 @@ public:
     cplx *tail[2] = {nullptr, nullptr};
     double *scale[2] = {nullptr, nullptr};
     unsigned long long *max2 = nullptr;
-    int *W = nullptr;
+    int *wexp[2] = {nullptr, nullptr};  // per matrix, ping-pong with body/tail/scale
     int *status = nullptr;
     cplx *Y = nullptr, *Z = nullptr;
     cplx *chY = nullptr, *chV = nullptr, *chH = nullptr;
@@ -118,6 +118,8 @@ public:
     int cur = 0;             // index of the body/tail/scale set holding the current level
     bool tree_valid = false;
     size_t res_deg = 0;      // degree of the transfer matrix of the last tree run
+    size_t start_n = 0, start_d = 0;  // matrices (all signals) / degree the tree run starts from
+    bool use_leaf = true;    // fuse coefficients + first levels (nft_kernels.h body_leaf)
 
     NftPlan(BE &be_, size_t D_, size_t M_, size_t batch_, int akns_disc_, int deg0_)
         : be(be_), D(D_), M(M_), batch(batch_), akns_disc(akns_disc_), deg0(deg0_)
@@ -158,9 +160,10 @@ public:
         if (topN > kMaxSplitN) return NFT_EC_NOT_YET_IMPLEMENTED;
         bool ok = true;
         for (int i = 0; i < 2; i++) {
-            ok = ok && alloc(body[i], 4 * plane) && alloc(tail[i], 4 * n0) && alloc(scale[i], n0);
+            ok = ok && alloc(body[i], 4 * plane) && alloc(tail[i], 4 * n0) && alloc(scale[i], n0)
+                 && alloc(wexp[i], n0);
         }
-        ok = ok && alloc(max2, n0) && alloc(W, batch) && alloc(status, 4);
+        ok = ok && alloc(max2, n0) && alloc(status, 4);
         {   // scratch of the split transforms: 4*n_in polynomials of N forward, 4*n_out inverse,
             // maximised over the levels that use them (N can exceed 2d when d is not 2^k)
             size_t needY = 0, needZ = 0, n = n0, d = (size_t)deg0;
@@ -192,8 +195,8 @@ public:
 
     void destroy()
     {
-        for (int i = 0; i < 2; i++) { be.free(body[i]); be.free(tail[i]); be.free(scale[i]); }
-        be.free(max2); be.free(W); be.free(status); be.free(Y); be.free(Z);
+        for (int i = 0; i < 2; i++) { be.free(body[i]); be.free(tail[i]); be.free(scale[i]); be.free(wexp[i]); }
+        be.free(max2); be.free(status); be.free(Y); be.free(Z);
         be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
     }
 
@@ -219,7 +222,6 @@ public:
     // ---- level 0 from samples (fnft__akns_fscatter.c:116-917) --------------------------------
     int run_coeffs(const void *d_q, const void *d_r, double eps_t, int kappa)
     {
-        be.memset0(W, batch * sizeof(int));
         be.memset0(status, 4 * sizeof(int));
         CoeffParams p;
         p.q = (const cplx *)d_q;
@@ -227,6 +229,7 @@ public:
         p.body = body[0];
         p.tail = tail[0];
         p.scale = scale[0];
+        p.wexp = wexp[0];
         p.status = status;
         p.plane = plane;
         p.eps_t = eps_t;
@@ -237,7 +240,19 @@ public:
         p.disc = akns_disc;
         p.deg = deg0;
         cur = 0;
+        const int spt = use_leaf ? leaf_spt(deg0) : 0;
+        if (spt > 1 && Dpad >= (size_t)spt) {
+            LeafParams lp;
+            lp.c = p;
+            lp.spt = spt;
+            if (!dispatch_leaf(be, lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
+            start_n = n0 / (size_t)spt;
+            start_d = (size_t)deg0 * (size_t)spt;
+            return NFT_SUCCESS;
+        }
         if (!dispatch_coeffs(be, p)) return NFT_EC_NOT_YET_IMPLEMENTED;
+        start_n = n0;
+        start_d = (size_t)deg0;
         return NFT_SUCCESS;
     }
 
@@ -265,23 +280,26 @@ public:
         be.h2d(body[0], hb.data(), hb.size() * sizeof(cplx));
         be.h2d(tail[0], ht.data(), ht.size() * sizeof(cplx));
         be.h2d(scale[0], hs.data(), hs.size() * sizeof(double));
-        be.memset0(W, batch * sizeof(int));
+        be.memset0(wexp[0], n0 * sizeof(int));
         be.memset0(status, 4 * sizeof(int));
         cur = 0;
+        start_n = n0;
+        start_d = (size_t)deg0;
         return NFT_SUCCESS;
     }
 
     // ---- product tree (fnft__poly_fmult.c:460-519) ---------------------------------------------
     int run_tree()
     {
-        size_t n = n0;          // matrices at the current level, all signals
-        size_t d = (size_t)deg0;
+        size_t n = start_n;     // matrices at the current level, all signals
+        size_t d = start_d;
         while (n / batch > 1) {
             TreeLevel L;
             L.body_in = body[cur]; L.tail_in = tail[cur]; L.scale_in = scale[cur];
             L.body_out = body[cur ^ 1]; L.tail_out = tail[cur ^ 1]; L.scale_out = scale[cur ^ 1];
             L.max2_out = max2;
-            L.W = W;
+            L.wexp_in = wexp[cur];
+            L.wexp_out = wexp[cur ^ 1];
             L.plane = plane;
             L.n_in = (int)n;
             L.d = (int)d;
@@ -380,7 +398,7 @@ public:
         C.Ybuf = chY; C.Vbuf = chV; C.Hbuf = nullptr;
         fill_chirp_geometry(C, Lc);
         C.contspec = (cplx *)d_contspec;
-        C.W = W;
+        C.W = wexp[cur];
         C.status = status;
         C.xi0 = cs.XI[0];
         C.eps_xi = eps_xi;
