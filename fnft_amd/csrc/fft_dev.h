@@ -137,6 +137,12 @@ template <int SIGN> struct RegDft<16, SIGN> {
 // must be carried across consecutive calls (one barrier per exchange is then sufficient).
 // DB = false: one buffer, two barriers per exchange.
 // ---------------------------------------------------------------------------------------------
+// LDS element index swizzle: the first pass of a transform writes element 8p+k from lane p, a
+// 128-byte lane stride that would hit the same banks 8 ways; XOR-ing the low three bits with the
+// next three spreads those writes over all banks and keeps every aligned group of 8 consecutive
+// elements a permutation of itself, so the lane-contiguous reads stay conflict-free.
+template <int N> FA_HD int lds_swz(int a) { return (N >= 64) ? (a ^ ((a >> 3) & 7)) : a; }
+
 template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S> struct FftPass {
     static constexpr int r = (NCUR < R) ? NCUR : R;
     static constexpr int J = R / r;     // butterflies per lane
@@ -161,7 +167,7 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S> struct FftPas
 #pragma unroll
                 for (int k = 1; k < r; k++) t[k] = t[k] * tw_dir<SIGN>(tw[(size_t)(p * k) * S]);
 #pragma unroll
-                for (int k = 0; k < r; k++) buf[(size_t)(q + S * (r * p + k)) * B + c] = t[k];
+                for (int k = 0; k < r; k++) buf[(size_t)lds_swz<N>(q + S * (r * p + k)) * B + c] = t[k];
             } else {
 #pragma unroll
                 for (int k = 0; k < r; k++) x[j + J * k] = t[k];
@@ -170,7 +176,7 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S> struct FftPas
         if constexpr (!last) {
             FA_SYNC();
 #pragma unroll
-            for (int i = 0; i < R; i++) x[i] = buf[(size_t)(v + (N / R) * i) * B + c];
+            for (int i = 0; i < R; i++) x[i] = buf[(size_t)lds_swz<N>(v + (N / R) * i) * B + c];
             parity ^= 1;
             FftPass<N, R, B, SIGN, DB, NCUR / r, S * r>::run(x, lds, v, c, tw, parity);
         }

@@ -6,7 +6,8 @@
 #pragma once
 #include "nft_kernels.h"
 
-constexpr int kRowLen = 4096;       // N2 of every split transform
+constexpr int kRowTree = 2048;      // N2 of the split transforms of the product tree
+constexpr int kRowChirp = 4096;     // N2 of the split transforms of the chirp z-transform
 constexpr int kFusedMaxN = 4096;    // largest pair product done by one workgroup
 constexpr int kSchoolMaxDeg = 3;    // direct products up to this input degree
 
@@ -50,6 +51,7 @@ template <int N> struct PairCfg {
     static constexpr int R = 8;
     static constexpr int THREADS = (N / R > 256) ? N / R : 256;
     static constexpr int B = THREADS / (N / R);
+    static constexpr bool DB = (N <= 2048);  // N = 4096: one 64 KB buffer + 64 KB twiddle table
 };
 template <int N> struct KPairFft {
     using Params = TreeLevel;
@@ -60,17 +62,20 @@ template <int N> struct KPairFft {
     static constexpr int MIN_WAVES = (C::THREADS > 256) ? 2 : 1;
     static constexpr size_t lds_bytes()
     {
-        return (N > C::R ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx) + (size_t)C::B * 8;
+        return ((N > C::R && C::DB) ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx)
+               + (N > C::R ? (size_t)N * sizeof(cplx) : 0) + (size_t)C::B * 8;
     }
-    static FA_DEV void body(const Params &p) { body_pair_fft<N, C::R, C::B>(p); }
+    static FA_DEV void body(const Params &p) { body_pair_fft<N, C::R, C::B, C::DB>(p); }
 };
 
 // ---- split transforms ------------------------------------------------------------------------
 template <int N1> struct ColCfg {
-    static constexpr int R = (N1 <= 16) ? N1 : (N1 <= 256 ? 8 : 16);
+    // N1 <= 16: one lane per column, no LDS.  Larger: 16 points per lane so that a tile is
+    // BC >= 8 columns wide (global rows of >= 128 bytes), one LDS buffer (two barriers/exchange).
+    static constexpr int R = (N1 <= 16) ? N1 : 16;
     static constexpr int THREADS = (N1 <= 256) ? 256 : 512;
     static constexpr int BC = THREADS / (N1 / R);
-    static constexpr bool DB = (N1 <= 256);
+    static constexpr bool DB = false;
     static constexpr size_t lds_bytes()
     {
         return (N1 > R) ? (size_t)(DB ? 2 : 1) * N1 * BC * sizeof(cplx) : 0;
@@ -93,10 +98,10 @@ template <int N1> struct KColInv {
 struct KMid {
     using Params = BigLevel;
     static constexpr int R = 8;
-    static constexpr int THREADS = kRowLen / R;
+    static constexpr int THREADS = kRowTree / R;
     static constexpr int MIN_WAVES = 2;
-    static constexpr size_t lds_bytes() { return (size_t)2 * kRowLen * sizeof(cplx); }
-    static FA_DEV void body(const Params &p) { body_mid<kRowLen, R>(p); }
+    static constexpr size_t lds_bytes() { return (size_t)3 * kRowTree * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_mid<kRowTree, R>(p); }
 };
 template <int N1> struct KChirpColFwd {
     using Params = ChirpParams;
@@ -115,9 +120,9 @@ template <int N1> struct KChirpColInv {
 struct KChirpRows {
     using Params = ChirpParams;
     static constexpr int R = 8;
-    static constexpr int THREADS = kRowLen / R;
-    static constexpr size_t lds_bytes() { return (size_t)2 * kRowLen * sizeof(cplx); }
-    static FA_DEV void body(const Params &p) { body_chirp_rows<kRowLen, R, true>(p); }
+    static constexpr int THREADS = kRowChirp / R;
+    static constexpr size_t lds_bytes() { return (size_t)2 * kRowChirp * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_chirp_rows<kRowChirp, R, true>(p); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -201,7 +206,7 @@ template <class BE> bool dispatch_col_fwd(BE &be, const BigLevel &G)
 {
     const int polys = 4 * G.L.n_in;
     switch (G.N1) {
-#define X(n1) case n1: be.template run<KColFwd<n1>>(kRowLen / ColCfg<n1>::BC, polys, G); return true;
+#define X(n1) case n1: be.template run<KColFwd<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
         FA_FOR_EACH_N1(X)
 #undef X
     default: return false;
@@ -211,7 +216,7 @@ template <class BE> bool dispatch_col_inv(BE &be, const BigLevel &G)
 {
     const int polys = 4 * (G.L.n_in / 2);
     switch (G.N1) {
-#define X(n1) case n1: be.template run<KColInv<n1>>(kRowLen / ColCfg<n1>::BC, polys, G); return true;
+#define X(n1) case n1: be.template run<KColInv<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
         FA_FOR_EACH_N1(X)
 #undef X
     default: return false;
@@ -221,7 +226,7 @@ template <class BE> bool dispatch_chirp_col_fwd(BE &be, const ChirpParams &C)
 {
     const int jobs = C.batch * C.npoly + 1;
     switch (C.N1) {
-#define X(n1) case n1: be.template run<KChirpColFwd<n1>>(kRowLen / ColCfg<n1>::BC, jobs, C); return true;
+#define X(n1) case n1: be.template run<KChirpColFwd<n1>>(C.N2 / ColCfg<n1>::BC, jobs, C); return true;
         FA_FOR_EACH_N1(X)
 #undef X
     default: return false;
@@ -230,7 +235,7 @@ template <class BE> bool dispatch_chirp_col_fwd(BE &be, const ChirpParams &C)
 template <class BE> bool dispatch_chirp_col_inv(BE &be, const ChirpParams &C)
 {
     switch (C.N1) {
-#define X(n1) case n1: be.template run<KChirpColInv<n1>>(kRowLen / ColCfg<n1>::BC, C.batch, C); return true;
+#define X(n1) case n1: be.template run<KChirpColInv<n1>>(C.N2 / ColCfg<n1>::BC, C.batch, C); return true;
         FA_FOR_EACH_N1(X)
 #undef X
     default: return false;

@@ -480,33 +480,43 @@ template <int DEG> FA_DEV void body_pair_school(const TreeLevel &L)
 // IO supplies the loads/stores so that the same body serves a whole tree level (TreeIO) and the
 // row step of a transform that is split across workgroups (MidIO).
 // ---------------------------------------------------------------------------------------------
-template <int N, int R, int B, class IO> FA_DEV void pair_product_core(IO &io, cplx *lds, const cplx *tw)
+// Twiddle tables are copied into LDS once per workgroup: every radix pass needs r-1 table
+// entries per butterfly, and at 1-2 waves per SIMD a global (L2) fetch per pass is pure stall.
+template <int N, int T> FA_DEV cplx *stage_twiddles(cplx *dst, const cplx *__restrict__ src)
+{
+    for (int j = FA_TID; j < N; j += T) dst[j] = src[j];
+    FA_SYNC();
+    return dst;
+}
+
+template <int N, int R, int B, bool DB, class IO>
+FA_DEV void pair_product_core(IO &io, cplx *lds, const cplx *tw)
 {
     const int tid = FA_TID;
     const int c = tid % B, v = tid / B;
     int parity = 0;
     cplx a[4][R];
+    // all four loads are issued before the first transform so that their latency overlaps it
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        io.load(0, e, a[e], v, c);
-        fft_wg<N, R, B, -1>(a[e], lds, v, c, tw, parity);
-    }
+    for (int e = 0; e < 4; e++) io.load(0, e, a[e], v, c);
+#pragma unroll
+    for (int e = 0; e < 4; e++) fft_wg<N, R, B, -1, DB>(a[e], lds, v, c, tw, parity);
 #pragma unroll
     for (int col = 0; col < 2; col++) {
         cplx b1[R], b2[R];
         io.load(1, col, b1, v, c);
-        fft_wg<N, R, B, -1>(b1, lds, v, c, tw, parity);
         io.load(1, 2 + col, b2, v, c);
-        fft_wg<N, R, B, -1>(b2, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB>(b1, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB>(b2, lds, v, c, tw, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const cplx x1 = b1[i], x2 = b2[i];
             b1[i] = cfma(a[1][i], x2, a[0][i] * x1);
             b2[i] = cfma(a[3][i], x2, a[2][i] * x1);
         }
-        fft_wg<N, R, B, +1>(b1, lds, v, c, tw, parity);
+        fft_wg<N, R, B, +1, DB>(b1, lds, v, c, tw, parity);
         io.store(col, b1, v, c, lds, parity);
-        fft_wg<N, R, B, +1>(b2, lds, v, c, tw, parity);
+        fft_wg<N, R, B, +1, DB>(b2, lds, v, c, tw, parity);
         io.store(2 + col, b2, v, c, lds, parity);
     }
 }
@@ -602,18 +612,22 @@ template <int N, int R, int B> struct TreeIO {
     }
 };
 
-// LDS: 2*N*B transform buffers (N > R) or one N*B staging buffer (N == R), then B u64 slots for
-// the per-pair maxima.
-template <int N, int R, int B> FA_DEV void body_pair_fft(const TreeLevel &L)
+// LDS: transform buffers (2*N*B, or N*B when !DB; N == R: one N*B staging buffer), the twiddle
+// table (N entries, N > R), then B u64 slots for the per-pair maxima.
+template <int N, int R, int B, bool DB> FA_DEV void body_pair_fft(const TreeLevel &L)
 {
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
-    unsigned long long *mx = (unsigned long long *)(lds + (N > R ? (size_t)2 * N * B : (size_t)N * B));
+    constexpr size_t kBuf = (N > R) ? (size_t)(DB ? 2 : 1) * N * B : (size_t)N * B;
+    cplx *twl = lds + kBuf;
+    unsigned long long *mx = (unsigned long long *)(twl + (N > R ? N : 0));
     const int tid = FA_TID;
     const int c = tid % B, v = tid / B;
     if (v == 0) mx[c] = 0ull;
+    const cplx *tw = L.tw;
+    if (N > R) tw = stage_twiddles<N, B *(N / R)>(twl, L.tw);
     TreeIO<N, R, B> io(L, c);
-    pair_product_core<N, R, B>(io, lds, L.tw);
+    pair_product_core<N, R, B, DB>(io, lds, tw);
     // every lane's first fft_wg exchange has passed a barrier after mx was zeroed when N > R;
     // for N == R (single pass, no barrier) the group is one lane, so order is trivial.
     if (N > R) {
@@ -715,7 +729,8 @@ template <int N2, int R> FA_DEV void body_mid(const BigLevel &G)
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
     MidIO<N2, R> io(G);
-    pair_product_core<N2, R, 1>(io, lds, G.tw2);
+    const cplx *tw = stage_twiddles<N2, N2 / R>(lds + (size_t)2 * N2, G.tw2);
+    pair_product_core<N2, R, 1, true>(io, lds, tw);
 }
 
 // column step of the inverse transform of every output polynomial

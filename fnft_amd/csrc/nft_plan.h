@@ -92,7 +92,8 @@ inline size_t nft_product_len(size_t d)
 
 constexpr int kFineLog2 = 12;           // master twiddle: NMAX = 2^24
 constexpr int kMaxTwTable = 4096;       // per-length tables up to this length
-constexpr size_t kMaxSplitN = (size_t)kRowLen * 1024;
+constexpr size_t kMaxSplitTree = (size_t)kRowTree * 1024;
+constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 1024;
 
 template <class BE> class NftPlan {
 public:
@@ -157,7 +158,7 @@ public:
         if (D < 1 || batch < 1 || deg0 < 1) return NFT_EC_INVALID_ARGUMENT;
         // largest product transform of the tree and chirp length must be within the split limits
         const size_t topN = (Dpad > 1) ? nft_product_len(Dpad / 2 * (size_t)deg0) : 2;
-        if (topN > kMaxSplitN) return NFT_EC_NOT_YET_IMPLEMENTED;
+        if (topN > kMaxSplitTree) return NFT_EC_NOT_YET_IMPLEMENTED;
         bool ok = true;
         for (int i = 0; i < 2; i++) {
             ok = ok && alloc(body[i], 4 * plane) && alloc(tail[i], 4 * n0) && alloc(scale[i], n0)
@@ -181,8 +182,8 @@ public:
         if (M > 0) {
             const size_t Np = D * (size_t)deg0 + 1;
             Lc = nft_nextpow2(Np + M - 1);
-            if (Lc < 2 * (size_t)kRowLen) Lc = 2 * (size_t)kRowLen;
-            if (Lc > kMaxSplitN) return NFT_EC_NOT_YET_IMPLEMENTED;
+            if (Lc < 2 * (size_t)kRowChirp) Lc = 2 * (size_t)kRowChirp;
+            if (Lc > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
             ok = ok && alloc(chY, batch * 2 * Lc) && alloc(chV, Lc);
         }
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
@@ -315,11 +316,11 @@ public:
                 BigLevel G;
                 G.L = L;
                 G.Y = Y; G.Z = Z;
-                G.N2 = kRowLen;
-                G.N1 = (int)(N / kRowLen);
+                G.N2 = kRowTree;
+                G.N1 = (int)(N / kRowTree);
                 G.btw = big_tw(N);
                 G.tw1 = (G.N1 >= 2) ? tw_table((size_t)G.N1) : nullptr;
-                G.tw2 = tw_table(kRowLen);
+                G.tw2 = tw_table(kRowTree);
                 ok = dispatch_col_fwd(be, G);
                 if (ok) {
                     be.template run<KMid>((int)(n / 2) * G.N1, 1, G);
@@ -361,11 +362,11 @@ public:
 
     void fill_chirp_geometry(ChirpParams &C, size_t L)
     {
-        C.N2 = kRowLen;
-        C.N1 = (int)(L / kRowLen);
+        C.N2 = kRowChirp;
+        C.N1 = (int)(L / kRowChirp);
         C.btw = big_tw(L);
         C.tw1 = tw_table((size_t)C.N1);
-        C.tw2 = tw_table(kRowLen);
+        C.tw2 = tw_table(kRowChirp);
         C.jobs_per_group = 2;
     }
 
@@ -430,8 +431,8 @@ public:
     {
         NftPlan pl(be, 2, 0, 1, 0, 1);  // only the twiddle tables of the plan are used
         size_t L = nft_nextpow2(deg + 1 + Mo - 1);
-        if (L < 2 * (size_t)kRowLen) L = 2 * (size_t)kRowLen;
-        if (L > kMaxSplitN) return NFT_EC_NOT_YET_IMPLEMENTED;
+        if (L < 2 * (size_t)kRowChirp) L = 2 * (size_t)kRowChirp;
+        if (L > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
         bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, (size_t)1 << kFineLog2);
         cplx *dp = nullptr, *dY = nullptr, *dV = nullptr, *dH = nullptr;
         int *dstatus = nullptr;
