@@ -53,19 +53,20 @@ template <int N> struct PairCfg {
     static constexpr int B = THREADS / (N / R);
     static constexpr bool DB = (N <= 2048);  // N = 4096: one 64 KB buffer + 64 KB twiddle table
 };
-template <int N> struct KPairFft {
+template <int N, int NE> struct KPairFft {
     using Params = TreeLevel;
     using C = PairCfg<N>;
     static constexpr int THREADS = C::THREADS;
-    // 1 wave/SIMD for 256-lane groups (no scratch spills at ~400 registers); the 512-lane
-    // N = 4096 group needs 2 waves/SIMD to be resident at all
-    static constexpr int MIN_WAVES = (C::THREADS > 256) ? 2 : 1;
+    // general form: 1 wave/SIMD for 256-lane groups (no scratch spills at ~400 registers); the
+    // 512-lane N = 4096 group needs 2 waves/SIMD to be resident at all.  The symmetric form
+    // holds half the spectra and fits 2 waves/SIMD.
+    static constexpr int MIN_WAVES = (C::THREADS > 256 || NE == 2) ? 2 : 1;
     static constexpr size_t lds_bytes()
     {
         return ((N > C::R && C::DB) ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx)
                + (N > C::R ? (size_t)N * sizeof(cplx) : 0) + (size_t)C::B * 8;
     }
-    static FA_DEV void body(const Params &p) { body_pair_fft<N, C::R, C::B, C::DB>(p); }
+    static FA_DEV void body(const Params &p) { body_pair_fft<N, C::R, C::B, C::DB, NE>(p); }
 };
 
 // ---- split transforms ------------------------------------------------------------------------
@@ -95,13 +96,13 @@ template <int N1> struct KColInv {
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
     static FA_DEV void body(const Params &p) { body_col_inv<N1, C::R, C::BC, C::DB>(p); }
 };
-struct KMid {
+template <int NE> struct KMid {
     using Params = BigLevel;
     static constexpr int R = 8;
     static constexpr int THREADS = kRowTree / R;
     static constexpr int MIN_WAVES = 2;
     static constexpr size_t lds_bytes() { return (size_t)3 * kRowTree * sizeof(cplx); }
-    static FA_DEV void body(const Params &p) { body_mid<kRowTree, R>(p); }
+    static FA_DEV void body(const Params &p) { body_mid<kRowTree, R, NE>(p); }
 };
 template <int N1> struct KChirpColFwd {
     using Params = ChirpParams;
@@ -181,7 +182,14 @@ template <class BE, int N> void run_pair_fft(BE &be, const TreeLevel &L)
 {
     const int pairs = L.n_in / 2;
     constexpr int B = PairCfg<N>::B;
-    be.template run<KPairFft<N>>((pairs + B - 1) / B, 1, L);
+    if (L.ne == 4) be.template run<KPairFft<N, 4>>((pairs + B - 1) / B, 1, L);
+    else be.template run<KPairFft<N, 2>>((pairs + B - 1) / B, 1, L);
+}
+template <class BE> void run_mid(BE &be, const BigLevel &G)
+{
+    const int g = (G.L.n_in / 2) * G.N1;
+    if (G.L.ne == 4) be.template run<KMid<4>>(g, 1, G);
+    else be.template run<KMid<2>>(g, 1, G);
 }
 template <class BE> bool dispatch_pair_fft(BE &be, const TreeLevel &L, int N)
 {
@@ -204,7 +212,7 @@ template <class BE> bool dispatch_pair_fft(BE &be, const TreeLevel &L, int N)
 
 template <class BE> bool dispatch_col_fwd(BE &be, const BigLevel &G)
 {
-    const int polys = 4 * G.L.n_in;
+    const int polys = G.L.ne * G.L.n_in;
     switch (G.N1) {
 #define X(n1) case n1: be.template run<KColFwd<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
         FA_FOR_EACH_N1(X)
@@ -214,7 +222,7 @@ template <class BE> bool dispatch_col_fwd(BE &be, const BigLevel &G)
 }
 template <class BE> bool dispatch_col_inv(BE &be, const BigLevel &G)
 {
-    const int polys = 4 * (G.L.n_in / 2);
+    const int polys = G.L.ne * (G.L.n_in / 2);
     switch (G.N1) {
 #define X(n1) case n1: be.template run<KColInv<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
         FA_FOR_EACH_N1(X)

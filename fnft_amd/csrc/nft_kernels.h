@@ -41,6 +41,8 @@ struct TreeLevel {
     int d;                         // their degree
     int pairs_per_signal;          // (n_in/2)/batch
     const cplx *tw;                // exp(-2 pi i j/N) table of the transform length used
+    int ne;                        // stored entries per matrix: 4 general, 2 symmetric (11, 21)
+    int kappa;                     // +1 focusing / -1 defocusing (symmetric form only)
 };
 
 // floor(log2(sqrt(m2))) for m2 > 0 (normal), exactly, from the exponent field
@@ -138,6 +140,7 @@ struct CoeffParams {
     double *scale;       // n
     int *wexp;           // n: exponent taken out (0 at level 0, set by the leaf kernel)
     int *status;         // bit 0: MODAL step-size check failed
+    int ne;              // stored entries per matrix: 4 general, 2 symmetric (11 and 21)
     size_t plane;
     double eps_t;
     int D, Dpad, batch, kappa;
@@ -271,14 +274,21 @@ template <int DEG> FA_DEV void body_coeffs(const CoeffParams &P)
         if (!sample_coeffs<DEG>(P.disc, P.eps_t, q, r, m)) fa_atomic_or_i32(P.status, 1);
     } else {
         coeffs_zero(m);
-        m.p[0][0] = cmake(1.0, 0.0);
-        m.p[3][0] = cmake(1.0, 0.0);
+        if (P.ne == 4) {
+            m.p[0][0] = cmake(1.0, 0.0);
+            m.p[3][0] = cmake(1.0, 0.0);
+        } else {
+            m.p[0][DEG] = cmake(1.0, 0.0);
+            m.p[3][0] = cmake(1.0, 0.0);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
+        if (P.ne == 2 && (e & 1)) continue;
+        const int s = (P.ne == 2) ? (e >> 1) : e;
 #pragma unroll
-        for (int k = 0; k < DEG; k++) P.body[(size_t)e * P.plane + (size_t)gid * DEG + k] = m.p[e][k];
-        P.tail[(size_t)e * n + gid] = m.p[e][DEG];
+        for (int k = 0; k < DEG; k++) P.body[(size_t)s * P.plane + (size_t)gid * DEG + k] = m.p[e][k];
+        P.tail[(size_t)s * n + gid] = m.p[e][DEG];
     }
     P.scale[gid] = 1.0;
     P.wexp[gid] = 0;
@@ -336,8 +346,13 @@ template <int DEG> FA_DEV bool leaf_sample(const CoeffParams &P, int b, long lon
         return sample_coeffs<DEG>(P.disc, P.eps_t, q, r, m);
     }
     coeffs_zero(m);
-    m.p[0][0] = cmake(1.0, 0.0);
-    m.p[3][0] = cmake(1.0, 0.0);
+    if (P.ne == 4) {   // z^deg * I, fnft__poly_fmult.c:422-438
+        m.p[0][0] = cmake(1.0, 0.0);
+        m.p[3][0] = cmake(1.0, 0.0);
+    } else {           // zero-sample matrix diag(1, z^deg): keeps the NSE symmetry
+        m.p[0][DEG] = cmake(1.0, 0.0);
+        m.p[3][0] = cmake(1.0, 0.0);
+    }
     return true;
 }
 
@@ -400,13 +415,15 @@ template <int DEG, int SPT> FA_DEV void body_leaf(const LeafParams &LP)
     const int total = (int)nvalid * d;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
+        if (P.ne == 2 && (e & 1)) continue;          // symmetric form stores 11 and 21 only
+        const int s = (P.ne == 2) ? (e >> 1) : e;    // destination plane
         if (active) {
 #pragma unroll
             for (int k = 0; k < d; k++) stage[(size_t)tid * d + ((k + tid) % d)] = acc[e][k] * sc;
-            P.tail[(size_t)e * n_out + gid] = acc[e][d] * sc;
+            P.tail[(size_t)s * n_out + gid] = acc[e][d] * sc;
         }
         FA_SYNC();
-        cplx *out0 = P.body + (size_t)e * P.plane + (size_t)g0 * d;
+        cplx *out0 = P.body + (size_t)s * P.plane + (size_t)g0 * d;
         for (int m = tid; m < total; m += FA_BDIM) {
             const int t2 = m / d, k2 = m - t2 * d;
             out0[m] = stage[(size_t)t2 * d + ((k2 + t2) % d)];
@@ -474,9 +491,19 @@ template <int DEG> FA_DEV void body_pair_school(const TreeLevel &L)
 
 // ---------------------------------------------------------------------------------------------
 // K2b: FFT pair product, one group of N/R lanes per pair, B pairs per workgroup.
-// A's four spectra stay in registers; B is streamed one column at a time:
-//   C(:,col) = A * B(:,col)  ->  2 forward transforms, 8 complex multiply-adds per bin,
-//   2 inverse transforms, stored; total 8 forward + 4 inverse as in the reference.
+//
+// General form (NE = 4 stored entries): A's four spectra stay in registers; B is streamed one
+// column at a time:  C(:,col) = A * B(:,col)  ->  2 forward transforms, 8 complex multiply-adds
+// per bin, 2 inverse transforms, stored; total 8 forward + 4 inverse as in the reference.
+//
+// Symmetric form (NE = 2, NSE with r = -kappa*conj(q)): every transfer matrix of degree d obeys
+//     p22[k] = conj(p11[d-k]),   p12[k] = -kappa*conj(p21[d-k])        (highest power first),
+// a property products preserve.  Only the first column (11 -> plane 0, 21 -> plane 1) is stored
+// and transformed; on the transform grid  X22 = g*conj(X11),  X12 = -kappa*g*conj(X21)  with
+// g[m] = exp(-2 pi i d m / N)  (= (-1)^m when N = 2d).  4 forward + 2 inverse transforms, half
+// the HBM traffic, half the registers.  The numbers produced are the ones the general form
+// produces up to rounding (tests compare both with the oracle).
+//
 // IO supplies the loads/stores so that the same body serves a whole tree level (TreeIO) and the
 // row step of a transform that is split across workgroups (MidIO).
 // ---------------------------------------------------------------------------------------------
@@ -521,7 +548,56 @@ FA_DEV void pair_product_core(IO &io, cplx *lds, const cplx *tw)
     }
 }
 
-template <int N, int R, int B> struct TreeIO {
+template <int N, int R, int B, bool DB, class IO>
+FA_DEV void pair_product_core_sym(IO &io, cplx *lds, const cplx *tw, int kappa)
+{
+    const int tid = FA_TID;
+    const int c = tid % B, v = tid / B;
+    int parity = 0;
+    cplx a11[R], a21[R], b11[R], b21[R];
+    io.load(0, 0, a11, v, c);
+    io.load(0, 1, a21, v, c);
+    io.load(1, 0, b11, v, c);
+    io.load(1, 1, b21, v, c);
+    fft_wg<N, R, B, -1, DB>(a11, lds, v, c, tw, parity);
+    fft_wg<N, R, B, -1, DB>(a21, lds, v, c, tw, parity);
+    fft_wg<N, R, B, -1, DB>(b11, lds, v, c, tw, parity);
+    fft_wg<N, R, B, -1, DB>(b21, lds, v, c, tw, parity);
+    const double mk = (double)(-kappa);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx g = io.gfac(v, i, tw);
+        const cplx gb = g * b21[i];                       // g * B21
+        const cplx c11 = cfma(cconj(a21[i]) * mk, gb, a11[i] * b11[i]);  // A11 B11 - k g A21* B21
+        const cplx c21 = cfma(cconj(a11[i]), gb, a21[i] * b11[i]);       // A21 B11 +   g A11* B21
+        b11[i] = c11;
+        b21[i] = c21;
+    }
+    fft_wg<N, R, B, +1, DB>(b11, lds, v, c, tw, parity);
+    io.store(0, b11, v, c, lds, parity);
+    fft_wg<N, R, B, +1, DB>(b21, lds, v, c, tw, parity);
+    io.store(1, b21, v, c, lds, parity);
+}
+
+// constant term ("tail") of entry e / plane s of the product of two matrices given the tails
+// and, for the symmetric form, the leading coefficients of the left factor
+struct TailSet {
+    cplx tA[4], tB[4];   // general: 4 tails each; symmetric: [0] = 11, [1] = 21
+    cplx leadA[2];       // symmetric: leading coefficients of A11, A21
+};
+FA_DEV cplx tail_product_general(const TailSet &t, int e)
+{
+    const int row = e >> 1, col = e & 1;
+    return cfma(t.tA[2 * row + 1], t.tB[2 + col], t.tA[2 * row] * t.tB[col]);
+}
+FA_DEV cplx tail_product_sym(const TailSet &t, int s, int kappa)
+{
+    // A12[d] = -kappa*conj(A21[0]),  A22[d] = conj(A11[0])
+    if (s == 0) return cfma(cconj(t.leadA[1]) * (double)(-kappa), t.tB[1], t.tA[0] * t.tB[0]);
+    return cfma(cconj(t.leadA[0]), t.tB[1], t.tA[1] * t.tB[0]);
+}
+
+template <int N, int R, int B, int NE> struct TreeIO {
     const TreeLevel &L;
     long long P;      // pair handled by this lane's group
     bool active;
@@ -540,7 +616,7 @@ template <int N, int R, int B> struct TreeIO {
     {
         return L.tail_in[(size_t)e * L.n_in + 2 * P + which] * sc[which];
     }
-    // which: 0 = left factor (A), 1 = right factor (B)
+    // which: 0 = left factor (A), 1 = right factor (B); e = plane
     FA_DEV void load(int which, int e, cplx (&x)[R], int v, int)
     {
         const int d = L.d;
@@ -556,16 +632,34 @@ template <int N, int R, int B> struct TreeIO {
             x[i] = val;
         }
     }
+    // g[m] = exp(-2 pi i d m / N) for the bin held in register i
+    FA_DEV cplx gfac(int v, int i, const cplx *tw) const
+    {
+        const int m = v + (N / R) * i;
+        const int j = (int)(((long long)L.d * m) % N);
+        return tw[j];
+    }
     FA_DEV cplx tail_product(int e) const
     {
-        const int row = e >> 1, col = e & 1;
-        return cfma(tail(0, 2 * row + 1), tail(1, 2 + col), tail(0, 2 * row) * tail(1, col));
+        TailSet t;
+        if (NE == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { t.tA[q] = tail(0, q); t.tB[q] = tail(1, q); }
+            return tail_product_general(t, e);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            t.tA[q] = tail(0, q);
+            t.tB[q] = tail(1, q);
+            t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sc[0];
+        }
+        return tail_product_sym(t, e, L.kappa);
     }
     // Results leave through LDS when a workgroup holds several pairs (B > 1): lane (v, c) owns a
     // strided sliver of pair c, and 16-byte stores at a 2d*16-byte lane stride reach HBM as
-    // partial lines (measured 5x-20x slower than full lines).  The idle transform buffer
-    // lds[parity] is the staging area (rows rotated by c against bank conflicts); flipping the
-    // parity afterwards keeps the one-barrier-per-exchange hand-over of fft_wg valid.
+    // partial lines.  The idle transform buffer lds[parity] is the staging area (rows rotated
+    // by c against bank conflicts); flipping the parity afterwards keeps the
+    // one-barrier-per-exchange hand-over of fft_wg valid.
     FA_DEV void store(int e, cplx (&x)[R], int v, int c, cplx *lds, int &parity)
     {
         const int d2 = 2 * L.d;
@@ -614,7 +708,7 @@ template <int N, int R, int B> struct TreeIO {
 
 // LDS: transform buffers (2*N*B, or N*B when !DB; N == R: one N*B staging buffer), the twiddle
 // table (N entries, N > R), then B u64 slots for the per-pair maxima.
-template <int N, int R, int B, bool DB> FA_DEV void body_pair_fft(const TreeLevel &L)
+template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const TreeLevel &L)
 {
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
@@ -626,8 +720,9 @@ template <int N, int R, int B, bool DB> FA_DEV void body_pair_fft(const TreeLeve
     if (v == 0) mx[c] = 0ull;
     const cplx *tw = L.tw;
     if (N > R) tw = stage_twiddles<N, B *(N / R)>(twl, L.tw);
-    TreeIO<N, R, B> io(L, c);
-    pair_product_core<N, R, B, DB>(io, lds, tw);
+    TreeIO<N, R, B, NE> io(L, c);
+    if (NE == 4) pair_product_core<N, R, B, DB>(io, lds, tw);
+    else pair_product_core_sym<N, R, B, DB>(io, lds, tw, L.kappa);
     // every lane's first fft_wg exchange has passed a barrier after mx was zeroed when N > R;
     // for N == R (single pass, no barrier) the group is one lane, so order is trivial.
     if (N > R) {
@@ -697,7 +792,8 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLeve
     }
 }
 
-// row step: one workgroup per (pair, k1): 8 forward row transforms, products, 4 inverse
+// row step: one workgroup per (pair, k1): forward row transforms of every stored entry of both
+// factors, products, inverse row transforms (8 + 4 general, 4 + 2 symmetric)
 template <int N2, int R> struct MidIO {
     const BigLevel &G;
     long long P;
@@ -714,6 +810,14 @@ template <int N2, int R> struct MidIO {
 #pragma unroll
         for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i];
     }
+    // g = exp(-2 pi i d k / N) at bin k = k1 + N1*k2, k2 = v + (N2/R)*i
+    FA_DEV cplx gfac(int v, int i, const cplx *) const
+    {
+        const long long N = (long long)G.N1 * N2;
+        const long long kbin = (long long)k1 + (long long)G.N1 * (v + (N2 / R) * i);
+        const long long j = ((long long)G.L.d * kbin) % N;
+        return big_twiddle(G.btw, (unsigned)j);
+    }
     FA_DEV void store(int e, cplx (&x)[R], int v, int, cplx *, int &)
     {
         const int n_out = G.L.n_in / 2;
@@ -724,13 +828,14 @@ template <int N2, int R> struct MidIO {
     }
 };
 
-template <int N2, int R> FA_DEV void body_mid(const BigLevel &G)
+template <int N2, int R, int NE> FA_DEV void body_mid(const BigLevel &G)
 {
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
     MidIO<N2, R> io(G);
     const cplx *tw = stage_twiddles<N2, N2 / R>(lds + (size_t)2 * N2, G.tw2);
-    pair_product_core<N2, R, 1, true>(io, lds, tw);
+    if (NE == 4) pair_product_core<N2, R, 1, true>(io, lds, tw);
+    else pair_product_core_sym<N2, R, 1, true>(io, lds, tw, G.L.kappa);
 }
 
 // column step of the inverse transform of every output polynomial
@@ -770,12 +875,22 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
         if (idx == 0) {
             // tails of the two factors -> constant term of the product, un-alias coefficient 0
             const double sA = L.scale_in[2 * P], sB = L.scale_in[2 * P + 1];
-            const int row = e >> 1, col = e & 1;
-            const cplx a0 = L.tail_in[(size_t)(2 * row) * L.n_in + 2 * P] * sA;
-            const cplx a1 = L.tail_in[(size_t)(2 * row + 1) * L.n_in + 2 * P] * sA;
-            const cplx b0 = L.tail_in[(size_t)(col)*L.n_in + 2 * P + 1] * sB;
-            const cplx b1 = L.tail_in[(size_t)(2 + col) * L.n_in + 2 * P + 1] * sB;
-            const cplx tp = cfma(a1, b1, a0 * b0);
+            TailSet t;
+            cplx tp;
+            if (L.ne == 4) {
+                for (int q = 0; q < 4; q++) {
+                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+                }
+                tp = tail_product_general(t, e);
+            } else {
+                for (int q = 0; q < 2; q++) {
+                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+                    t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
+                }
+                tp = tail_product_sym(t, e, L.kappa);
+            }
             if (N == d2) val = val - tp;
             L.tail_out[(size_t)e * n_out + P] = tp;
             m2 = fmax(m2, cnorm2(tp));
@@ -807,15 +922,28 @@ FA_DEV void body_finalize_scales(const TreeLevel &L)
 // padding contributes trailing zero coefficients which are dropped).
 // ---------------------------------------------------------------------------------------------
 struct ExportParams {
-    const cplx *body;   // 4 planes; signal b's matrix at b*deg_tot
-    const cplx *tail;   // 4 planes of batch
+    const cplx *body;   // ne planes; signal b's matrix at b*deg_tot
+    const cplx *tail;   // ne planes of batch
     const double *scale;
     cplx *out;          // batch * 4*(deg+1)
     size_t plane;
     long long deg_tot;  // Dpad*deg0
     long long deg;      // D*deg0
     int batch;
+    int ne;             // 4 general, 2 symmetric
+    int kappa;
 };
+// coefficient k (highest power first, k <= deg) of stored plane s of signal b.  General form:
+// identity padding z^deg0*I leaves TRAILING zeros, index k.  Symmetric form: padding with the
+// zero-sample matrix diag(1, z^deg0) leaves the first column unchanged as polynomials, i.e.
+// deg_tot - deg LEADING zeros, index k + (deg_tot - deg).
+FA_DEV cplx stored_coef(const cplx *body, const cplx *tail, size_t plane, long long deg_tot,
+                        long long deg, int batch, int ne, int s, int b, long long k)
+{
+    const long long kk = (ne == 2) ? k + (deg_tot - deg) : k;
+    if (kk < deg_tot) return body[(size_t)s * plane + (size_t)b * deg_tot + kk];
+    return tail[(size_t)s * batch + b];
+}
 FA_DEV void body_export_tm(const ExportParams &E)
 {
     const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
@@ -827,8 +955,16 @@ FA_DEV void body_export_tm(const ExportParams &E)
     const long long k = r % (E.deg + 1);
     const double sc = E.scale[b];
     cplx val;
-    if (k < E.deg_tot) val = E.body[(size_t)e * E.plane + (size_t)b * E.deg_tot + k];
-    else val = E.tail[(size_t)e * E.batch + b];
+    if (E.ne == 4) {
+        val = stored_coef(E.body, E.tail, E.plane, E.deg_tot, E.deg, E.batch, 4, e, b, k);
+    } else if (e == 0 || e == 2) {       // 11, 21 are stored
+        val = stored_coef(E.body, E.tail, E.plane, E.deg_tot, E.deg, E.batch, 2, e >> 1, b, k);
+    } else if (e == 3) {                 // p22[k] = conj(p11[deg-k])
+        val = cconj(stored_coef(E.body, E.tail, E.plane, E.deg_tot, E.deg, E.batch, 2, 0, b, E.deg - k));
+    } else {                             // p12[k] = -kappa*conj(p21[deg-k])
+        val = cconj(stored_coef(E.body, E.tail, E.plane, E.deg_tot, E.deg, E.batch, 2, 1, b, E.deg - k))
+              * (double)(-E.kappa);
+    }
     E.out[gid] = val * sc;
 }
 
@@ -851,7 +987,8 @@ struct ChirpParams {
     long long deg;       // polynomial degree actually evaluated
     int batch;
     int npoly;           // polynomials per signal (2 for nsev, 1 for stand-alone)
-    int entry[2];        // transfer-matrix entries to evaluate (0..3)
+    int entry[2];        // stored planes to evaluate (general: 0 and 2; symmetric: 0 and 1)
+    int ne;              // stored entries per matrix (4 general, 2 symmetric)
     // chirp
     double logA[2], logW[2];  // log A, log W (complex)
     long long M;
@@ -884,10 +1021,8 @@ FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k)
 {
     // coefficient k (highest power first) of polynomial `slot` of signal b
     if (C.poly) return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)k];
-    const int e = C.entry[slot];
-    const double sc = C.scale[b];
-    if (k < C.deg_tot) return C.body[(size_t)e * C.plane + (size_t)b * C.deg_tot + k] * sc;
-    return C.tail[(size_t)e * C.batch + b] * sc;
+    return stored_coef(C.body, C.tail, C.plane, C.deg_tot, C.deg, C.batch, C.ne, C.entry[slot], b, k)
+           * C.scale[b];
 }
 
 // column step (forward) of the chirp-premultiplied polynomials and of the chirp filter

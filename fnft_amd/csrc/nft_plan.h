@@ -121,6 +121,9 @@ public:
     size_t res_deg = 0;      // degree of the transfer matrix of the last tree run
     size_t start_n = 0, start_d = 0;  // matrices (all signals) / degree the tree run starts from
     bool use_leaf = true;    // fuse coefficients + first levels (nft_kernels.h body_leaf)
+    bool use_sym = true;     // NSE symmetry: store/transform only the first column (ne = 2)
+    int ne = 4;              // stored entries per matrix in the current tree run
+    int kappa_run = 1;
 
     NftPlan(BE &be_, size_t D_, size_t M_, size_t batch_, int akns_disc_, int deg0_)
         : be(be_), D(D_), M(M_), batch(batch_), akns_disc(akns_disc_), deg0(deg0_)
@@ -241,8 +244,14 @@ public:
         p.disc = akns_disc;
         p.deg = deg0;
         cur = 0;
+        kappa_run = kappa;
         const int spt = use_leaf ? leaf_spt(deg0) : 0;
-        if (spt > 1 && Dpad >= (size_t)spt) {
+        const bool leaf = spt > 1 && Dpad >= (size_t)spt;
+        // the symmetric form needs r = -kappa*conj(q) (no explicit r) and starts above the
+        // direct-product levels, which the leaf kernel guarantees
+        ne = (use_sym && leaf && d_r == nullptr && (size_t)deg0 * spt > (size_t)kSchoolMaxDeg) ? 2 : 4;
+        p.ne = ne;
+        if (leaf) {
             LeafParams lp;
             lp.c = p;
             lp.spt = spt;
@@ -284,6 +293,7 @@ public:
         be.memset0(wexp[0], n0 * sizeof(int));
         be.memset0(status, 4 * sizeof(int));
         cur = 0;
+        ne = 4;
         start_n = n0;
         start_d = (size_t)deg0;
         return NFT_SUCCESS;
@@ -305,6 +315,8 @@ public:
             L.n_in = (int)n;
             L.d = (int)d;
             L.pairs_per_signal = (int)(n / 2 / batch);
+            L.ne = ne;
+            L.kappa = kappa_run;
             const size_t N = nft_product_len(d);
             L.tw = (N <= (size_t)kMaxTwTable) ? tw_table(N) : nullptr;
             bool ok;
@@ -323,7 +335,7 @@ public:
                 G.tw2 = tw_table(kRowTree);
                 ok = dispatch_col_fwd(be, G);
                 if (ok) {
-                    be.template run<KMid>((int)(n / 2) * G.N1, 1, G);
+                    run_mid(be, G);
                     ok = dispatch_col_inv(be, G);
                 }
                 if (ok) be.template run<KFinalizeScales>((int)((n / 2 + 63) / 64), 1, L);
@@ -348,6 +360,8 @@ public:
         E.deg_tot = (long long)(Dpad * (size_t)deg0);
         E.deg = (long long)res_deg;
         E.batch = (int)batch;
+        E.ne = ne;
+        E.kappa = kappa_run;
         const long long tot = 4 * (E.deg + 1) * E.batch;
         be.template run<KExportTm>((int)((tot + 255) / 256), 1, E);
     }
@@ -391,8 +405,9 @@ public:
         C.deg = (long long)res_deg;
         C.batch = (int)batch;
         C.npoly = 2;
-        C.entry[0] = 0;  // H11, fnft_nsev.c:829
-        C.entry[1] = 2;  // H21, fnft_nsev.c:832
+        C.ne = ne;
+        C.entry[0] = 0;                    // H11, fnft_nsev.c:829
+        C.entry[1] = (ne == 4) ? 2 : 1;    // H21, fnft_nsev.c:832 (plane 1 in the symmetric form)
         C.logA[0] = lA.real(); C.logA[1] = lA.imag();
         C.logW[0] = lV.real(); C.logW[1] = lV.imag();
         C.M = (long long)M;
