@@ -51,7 +51,7 @@ template <int N> struct PairCfg {
     static constexpr int R = 8;
     static constexpr int THREADS = (N / R > 256) ? N / R : 256;
     static constexpr int B = THREADS / (N / R);
-    static constexpr bool DB = (N <= 2048);  // N = 4096: one 64 KB buffer + 64 KB twiddle table
+    static constexpr bool DB = (N <= 2048);  // N = 4096: one 64 KB buffer
 };
 template <int N, int NE> struct KPairFft {
     using Params = TreeLevel;
@@ -64,7 +64,8 @@ template <int N, int NE> struct KPairFft {
     static constexpr size_t lds_bytes()
     {
         return ((N > C::R && C::DB) ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx)
-               + (N > C::R ? (size_t)N * sizeof(cplx) : 0) + (size_t)C::B * 8;
+               + ((N > C::R && (N <= 512 || N == 4096)) ? (size_t)N * sizeof(cplx) : 0)
+               + (size_t)C::B * 8;
     }
     static FA_DEV void body(const Params &p) { body_pair_fft<N, C::R, C::B, C::DB, NE>(p); }
 };
@@ -101,7 +102,7 @@ template <int NE> struct KMid {
     static constexpr int R = 8;
     static constexpr int THREADS = kRowTree / R;
     static constexpr int MIN_WAVES = 2;
-    static constexpr size_t lds_bytes() { return (size_t)3 * kRowTree * sizeof(cplx); }
+    static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_mid<kRowTree, R, NE>(p); }
 };
 template <int N1> struct KChirpColFwd {

@@ -713,13 +713,15 @@ template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const 
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
     constexpr size_t kBuf = (N > R) ? (size_t)(DB ? 2 : 1) * N * B : (size_t)N * B;
+    // larger tables would halve the residency; N = 4096 runs one workgroup per CU anyway
+    constexpr bool kTwLds = (N > R) && (N <= 512 || N == 4096);
     cplx *twl = lds + kBuf;
-    unsigned long long *mx = (unsigned long long *)(twl + (N > R ? N : 0));
+    unsigned long long *mx = (unsigned long long *)(twl + (kTwLds ? N : 0));
     const int tid = FA_TID;
     const int c = tid % B, v = tid / B;
     if (v == 0) mx[c] = 0ull;
     const cplx *tw = L.tw;
-    if (N > R) tw = stage_twiddles<N, B *(N / R)>(twl, L.tw);
+    if (kTwLds) tw = stage_twiddles<N, B *(N / R)>(twl, L.tw);
     TreeIO<N, R, B, NE> io(L, c);
     if (NE == 4) pair_product_core<N, R, B, DB>(io, lds, tw);
     else pair_product_core_sym<N, R, B, DB>(io, lds, tw, L.kappa);
@@ -833,7 +835,7 @@ template <int N2, int R, int NE> FA_DEV void body_mid(const BigLevel &G)
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
     MidIO<N2, R> io(G);
-    const cplx *tw = stage_twiddles<N2, N2 / R>(lds + (size_t)2 * N2, G.tw2);
+    const cplx *tw = G.tw2;
     if (NE == 4) pair_product_core<N2, R, 1, true>(io, lds, tw);
     else pair_product_core_sym<N2, R, 1, true>(io, lds, tw, G.L.kappa);
 }
