@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "hipcc")
     objs = []
     cmds = [
-        [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c",
+        [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FNFT_AMD_DEFS", "").split() + ["-c",
          os.path.join(CSRC, "hip_backend.hip"), "-o", os.path.join(LIBDIR, "hip_backend.o")],
         [hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c",
          os.path.join(CSRC, "fnft_nsev_host.c"), "-o", os.path.join(LIBDIR, "fnft_nsev_host.o")],

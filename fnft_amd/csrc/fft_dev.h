@@ -121,6 +121,39 @@ template <int SIGN> struct RegDft<16, SIGN> {
     }
 };
 
+template <int SIGN> struct RegDft<32, SIGN> {
+    static FA_HD void run(cplx (&x)[32])
+    {
+        // w32^k = cos(k pi/16) + S i sin(k pi/16), k = 0..15
+        const double cs[16] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                               0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                               0.19509032201612826785, 0.0, -0.19509032201612826785, -0.38268343236508977173,
+                               -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
+                               -0.92387953251128675613, -0.98078528040323044913};
+        const double sn[16] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
+                               0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
+                               0.98078528040323044913, 1.0, 0.98078528040323044913, 0.92387953251128675613,
+                               0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474,
+                               0.38268343236508977173, 0.19509032201612826785};
+        const double S = (double)SIGN;
+        cplx e[16], o[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            e[k] = x[k] + x[k + 16];
+            o[k] = x[k] - x[k + 16];
+        }
+#pragma unroll
+        for (int k = 1; k < 16; k++) o[k] = (k == 8) ? mul_si<SIGN>(o[k]) : o[k] * cmake(cs[k], S * sn[k]);
+        RegDft<16, SIGN>::run(e);
+        RegDft<16, SIGN>::run(o);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            x[2 * k] = e[k];
+            x[2 * k + 1] = o[k];
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Workgroup-cooperative FFT of B interleaved length-N sequences, R points per lane.
 //

@@ -3,6 +3,7 @@
 // entry the C driver fnft_nsev_host.c calls).  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -147,6 +148,7 @@ FNFT_INT fnft_amd_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, 
     P->nse_disc = (int)discretization;
     P->pl = new (std::nothrow) Plan(P->be, D, M, batch, akns, nft_akns_degree(akns));
     if (!P->pl) { delete P; return FNFT_EC_NOMEM; }
+    if (const char *dbg = getenv("FNFT_AMD_DBG")) P->pl->dbg_flags = atoi(dbg);
     const int rc = P->pl->init();
     if (rc != NFT_SUCCESS || P->be.failed) {
         P->pl->destroy();

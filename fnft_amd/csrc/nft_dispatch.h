@@ -47,20 +47,24 @@ struct KExportTm {
 };
 
 // ---- fused pair product ----------------------------------------------------------------------
-template <int N> struct PairCfg {
-    static constexpr int R = 8;
+#ifndef FA_PAIR_R_SYM
+#define FA_PAIR_R_SYM 8
+#endif
+template <int N, int NE = 4> struct PairCfg {
+    // points per lane: 8; (experiment knob: the symmetric form can run with 4 for N <= 1024)
+    static constexpr int R = (NE == 2 && N <= 1024 && N >= 16) ? FA_PAIR_R_SYM : 8;
     static constexpr int THREADS = (N / R > 256) ? N / R : 256;
     static constexpr int B = THREADS / (N / R);
     static constexpr bool DB = (N <= 2048);  // N = 4096: one 64 KB buffer
 };
 template <int N, int NE> struct KPairFft {
     using Params = TreeLevel;
-    using C = PairCfg<N>;
+    using C = PairCfg<N, NE>;
     static constexpr int THREADS = C::THREADS;
     // general form: 1 wave/SIMD for 256-lane groups (no scratch spills at ~400 registers); the
     // 512-lane N = 4096 group needs 2 waves/SIMD to be resident at all.  The symmetric form
     // holds half the spectra and fits 2 waves/SIMD.
-    static constexpr int MIN_WAVES = (C::THREADS > 256 || NE == 2) ? 2 : 1;
+    static constexpr int MIN_WAVES = (C::THREADS > 256 || NE == 2) ? (C::R == 4 ? 4 : 2) : 1;
     static constexpr size_t lds_bytes()
     {
         return ((N > C::R && C::DB) ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx)
@@ -96,6 +100,20 @@ template <int N1> struct KColInv {
     static constexpr int THREADS = C::THREADS;
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
     static FA_DEV void body(const Params &p) { body_col_inv<N1, C::R, C::BC, C::DB>(p); }
+};
+template <int N1> struct BridgeCfg {
+    static constexpr int R = (N1 <= 16) ? N1 : 16;
+    static constexpr int THREADS = 256;
+    static constexpr int BC = THREADS / (N1 / R);
+    static constexpr bool DB = false;
+    static constexpr size_t lds_bytes() { return (N1 > R) ? (size_t)2 * N1 * BC * sizeof(cplx) : 0; }
+};
+template <int N1> struct KColBridge {
+    using Params = BigLevel;
+    using C = BridgeCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_col_bridge<N1, C::R, C::BC, C::DB>(p); }
 };
 template <int NE> struct KMid {
     using Params = BigLevel;
@@ -182,9 +200,9 @@ template <class BE> bool dispatch_pair_school(BE &be, const TreeLevel &L)
 template <class BE, int N> void run_pair_fft(BE &be, const TreeLevel &L)
 {
     const int pairs = L.n_in / 2;
-    constexpr int B = PairCfg<N>::B;
-    if (L.ne == 4) be.template run<KPairFft<N, 4>>((pairs + B - 1) / B, 1, L);
-    else be.template run<KPairFft<N, 2>>((pairs + B - 1) / B, 1, L);
+    constexpr int B4 = PairCfg<N, 4>::B, B2 = PairCfg<N, 2>::B;
+    if (L.ne == 4) be.template run<KPairFft<N, 4>>((pairs + B4 - 1) / B4, 1, L);
+    else be.template run<KPairFft<N, 2>>((pairs + B2 - 1) / B2, 1, L);
 }
 template <class BE> void run_mid(BE &be, const BigLevel &G)
 {
@@ -227,6 +245,17 @@ template <class BE> bool dispatch_col_inv(BE &be, const BigLevel &G)
     switch (G.N1) {
 #define X(n1) case n1: be.template run<KColInv<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
         FA_FOR_EACH_N1(X)
+#undef X
+    default: return false;
+    }
+}
+#define FA_FOR_EACH_BRIDGE_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256)
+template <class BE> bool dispatch_col_bridge(BE &be, const BigLevel &G)
+{
+    const int polys = G.L.ne * (G.L.n_in / 2);
+    switch (G.N1) {
+#define X(n1) case n1: be.template run<KColBridge<n1>>(G.N2 / BridgeCfg<n1>::BC, polys, G); return true;
+        FA_FOR_EACH_BRIDGE_N1(X)
 #undef X
     default: return false;
     }

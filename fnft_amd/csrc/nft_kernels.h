@@ -43,6 +43,7 @@ struct TreeLevel {
     const cplx *tw;                // exp(-2 pi i j/N) table of the transform length used
     int ne;                        // stored entries per matrix: 4 general, 2 symmetric (11, 21)
     int kappa;                     // +1 focusing / -1 defocusing (symmetric form only)
+    int dbg;                       // timing ablation (tests/gpu_debug only): 1 skip transforms, 2 skip loads, 4 skip stores
 };
 
 // floor(log2(sqrt(m2))) for m2 > 0 (normal), exactly, from the exponent field
@@ -555,14 +556,23 @@ FA_DEV void pair_product_core_sym(IO &io, cplx *lds, const cplx *tw, int kappa)
     const int c = tid % B, v = tid / B;
     int parity = 0;
     cplx a11[R], a21[R], b11[R], b21[R];
-    io.load(0, 0, a11, v, c);
-    io.load(0, 1, a21, v, c);
-    io.load(1, 0, b11, v, c);
-    io.load(1, 1, b21, v, c);
-    fft_wg<N, R, B, -1, DB>(a11, lds, v, c, tw, parity);
-    fft_wg<N, R, B, -1, DB>(a21, lds, v, c, tw, parity);
-    fft_wg<N, R, B, -1, DB>(b11, lds, v, c, tw, parity);
-    fft_wg<N, R, B, -1, DB>(b21, lds, v, c, tw, parity);
+    const int dbg = io.dbg();
+
+    if (!(dbg & 2)) {
+        io.load(0, 0, a11, v, c);
+        io.load(0, 1, a21, v, c);
+        io.load(1, 0, b11, v, c);
+        io.load(1, 1, b21, v, c);
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; i++) a11[i] = a21[i] = b11[i] = b21[i] = cmake(1.0 + v, 0.5 * i);
+    }
+    if (!(dbg & 1)) {
+        fft_wg<N, R, B, -1, DB>(a11, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB>(a21, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB>(b11, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB>(b21, lds, v, c, tw, parity);
+    }
     const double mk = (double)(-kappa);
 #pragma unroll
     for (int i = 0; i < R; i++) {
@@ -573,10 +583,11 @@ FA_DEV void pair_product_core_sym(IO &io, cplx *lds, const cplx *tw, int kappa)
         b11[i] = c11;
         b21[i] = c21;
     }
-    fft_wg<N, R, B, +1, DB>(b11, lds, v, c, tw, parity);
-    io.store(0, b11, v, c, lds, parity);
-    fft_wg<N, R, B, +1, DB>(b21, lds, v, c, tw, parity);
-    io.store(1, b21, v, c, lds, parity);
+    if (!(dbg & 1)) fft_wg<N, R, B, +1, DB>(b11, lds, v, c, tw, parity);
+    if (!(dbg & 4)) io.store(0, b11, v, c, lds, parity);
+    if (!(dbg & 1)) fft_wg<N, R, B, +1, DB>(b21, lds, v, c, tw, parity);
+    if (!(dbg & 4)) io.store(1, b21, v, c, lds, parity);
+    if (dbg & 4) io.sink(b11, b21);
 }
 
 // constant term ("tail") of entry e / plane s of the product of two matrices given the tails
@@ -631,6 +642,14 @@ template <int N, int R, int B, int NE> struct TreeIO {
             }
             x[i] = val;
         }
+    }
+    FA_DEV int dbg() const { return L.dbg; }
+    FA_DEV void sink(cplx (&x)[R], cplx (&y)[R])
+    {   // keeps ablated work alive: one lane may store
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; i++) s += x[i].x + y[i].y;
+        if (s == 1.2345e301) L.body_out[0] = cmake(s, s);
     }
     // g[m] = exp(-2 pi i d m / N) for the bin held in register i
     FA_DEV cplx gfac(int v, int i, const cplx *tw) const
@@ -756,6 +775,10 @@ struct BigLevel {
     const cplx *tw1; // table for N1
     const cplx *tw2; // table for N2
     int N1, N2;
+    // bridge to the next level (body_col_bridge): tables for 2*N1 and 2*N, Y holds unscaled data
+    const cplx *tw1x2;
+    BigTwiddle btw2;
+    int y_unscaled;  // row kernel multiplies by scale_in on load
 };
 
 // column step of the forward transform of every input polynomial of the level
@@ -785,12 +808,13 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLeve
     }
     int parity = 0;
     fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, G.tw1, parity);
+    // the twiddle w_N^{n2 k1} between column and row step is applied by the row kernel, where
+    // one set of R factors per lane serves every polynomial of the pair
     cplx *dst = G.Y + (size_t)poly * N1 * N2;
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int k1 = v + (N1 / R) * i;
-        const cplx w = big_twiddle(G.btw, (unsigned)k1 * (unsigned)n2);
-        dst[(size_t)k1 * N2 + n2] = x[i] * w;
+        dst[(size_t)k1 * N2 + n2] = x[i];
     }
 }
 
@@ -800,17 +824,36 @@ template <int N2, int R> struct MidIO {
     const BigLevel &G;
     long long P;
     int k1;
+    double sc[2];
     FA_DEV MidIO(const BigLevel &G_) : G(G_)
     {
         P = FA_BID / G.N1;
         k1 = FA_BID % G.N1;
+        sc[0] = G.y_unscaled ? G.L.scale_in[2 * P] : 1.0;
+        sc[1] = G.y_unscaled ? G.L.scale_in[2 * P + 1] : 1.0;
+    }
+    // w_N^{k1 n2} for element n2 = v + (N2/R)*i of this lane (same for every polynomial) =
+    // per-lane look-up w^{k1 v} times the workgroup-uniform factor w^{k1 (N2/R) i}; formed per
+    // element (no register array: the row kernel is at its VGPR budget)
+    FA_DEV cplx twiddle(cplx base, int i) const
+    {
+        return (i == 0) ? base : base * big_twiddle(G.btw, (unsigned)k1 * (unsigned)((N2 / R) * i));
     }
     FA_DEV void load(int which, int e, cplx (&x)[R], int v, int)
     {
         const int n_in = G.L.n_in;
         const cplx *src = G.Y + ((size_t)((size_t)e * n_in + 2 * P + which) * G.N1 + k1) * N2;
+        const cplx base = big_twiddle(G.btw, (unsigned)k1 * (unsigned)v) * sc[which];
 #pragma unroll
-        for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i];
+        for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i] * twiddle(base, i);
+    }
+    FA_DEV int dbg() const { return G.L.dbg; }
+    FA_DEV void sink(cplx (&x)[R], cplx (&y)[R])
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; i++) s += x[i].x + y[i].y;
+        if (s == 1.2345e301) G.Z[0] = cmake(s, s);
     }
     // g = exp(-2 pi i d k / N) at bin k = k1 + N1*k2, k2 = v + (N2/R)*i
     FA_DEV cplx gfac(int v, int i, const cplx *) const
@@ -824,9 +867,9 @@ template <int N2, int R> struct MidIO {
     {
         const int n_out = G.L.n_in / 2;
         cplx *dst = G.Z + ((size_t)((size_t)e * n_out + P) * G.N1 + k1) * N2;
-        const double inv = 1.0 / (double)N2;
+        const cplx base = big_twiddle(G.btw, (unsigned)k1 * (unsigned)v) * (1.0 / (double)N2);
 #pragma unroll
-        for (int i = 0; i < R; i++) dst[v + (N2 / R) * i] = x[i] * inv;
+        for (int i = 0; i < R; i++) dst[v + (N2 / R) * i] = x[i] * cconj(twiddle(base, i));
     }
 };
 
@@ -861,8 +904,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int k1 = v + (N1 / R) * i;
-        const cplx w = cconj(big_twiddle(G.btw, (unsigned)k1 * (unsigned)n2));
-        x[i] = src[(size_t)k1 * N2 + n2] * w;
+        x[i] = src[(size_t)k1 * N2 + n2];   // conj twiddle already applied by the row kernel
     }
     int parity = 0;
     fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, G.tw1, parity);
@@ -880,12 +922,14 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
             TailSet t;
             cplx tp;
             if (L.ne == 4) {
+#pragma unroll
                 for (int q = 0; q < 4; q++) {
                     t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
                     t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
                 }
                 tp = tail_product_general(t, e);
             } else {
+#pragma unroll
                 for (int q = 0; q < 2; q++) {
                     t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
                     t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
@@ -903,6 +947,100 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
         }
     }
     fa_atomic_max_u64(&L.max2_out[P], dbits(m2));
+}
+
+// Bridge between two consecutive split levels: inverse column step of level l (N = N1*N2)
+// immediately followed by the forward column step of level l+1 (2N = 2N1*N2) of the same
+// polynomial, in registers.  The degree-2d coefficients never go to HBM: only their maximum
+// (for the pending scale), the new tail, and coefficient 0 (the next level's "lead") are kept.
+// The pending scale is not known here, so Y' is written unscaled and the row kernel of level
+// l+1 applies scale_in on load (BigLevel::y_unscaled).
+//   grid.x = N2/BC tiles, grid.y = ne*n_out polynomials;  lanes hold R points of the inverse and
+//   2R points (upper half zero) of the forward transform.
+template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigLevel &G)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int poly = FA_BID_Y;
+    const int n_out = L.n_in / 2;
+    const int e = poly / n_out, P = poly % n_out;
+    const int N2 = G.N2;
+    const long long N = (long long)N1 * N2;
+    const int d2 = 2 * L.d;
+    const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    cplx x[2 * R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int k1 = v + (N1 / R) * i;
+        x[i] = src[(size_t)k1 * N2 + n2];   // conj twiddle already applied by the row kernel
+    }
+    int parity = 0;
+    {
+        cplx lo[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) lo[i] = x[i];
+        fft_wg<N1, R, BC, +1, DB>(lo, lds, v, c, G.tw1, parity);
+#pragma unroll
+        for (int i = 0; i < R; i++) x[i] = lo[i];
+    }
+    const double inv = 1.0 / (double)N1;
+    double m2 = 0.0;
+    // constant term of the product (needed by the lanes holding index 0 and index 2d)
+    auto tail_prod = [&]() -> cplx {
+        const double sA = L.scale_in[2 * P], sB = L.scale_in[2 * P + 1];
+        TailSet t;
+        if (L.ne == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+                t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+            }
+            return tail_product_general(t, e);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+            t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+            t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
+        }
+        return tail_product_sym(t, e, L.kappa);
+    };
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n1 = v + (N1 / R) * i;
+        const long long idx = (long long)n1 * N2 + n2;
+        cplx val = x[i] * inv;
+        cplx up = cmake(0.0, 0.0);   // element n1 + N1 of the zero-padded next-level column
+        if (idx == 0) {
+            const cplx tp = tail_prod();
+            if (N == d2) {
+                val = val - tp;      // un-alias coefficient 2d folded onto 0
+                up = tp;             // index 2d = N of the degree-2d polynomial: its tail
+            }
+            L.tail_out[(size_t)e * n_out + P] = tp;
+            // coefficient 0 is the only body element later levels read (tail products)
+            L.body_out[(size_t)e * L.plane + (size_t)P * d2] = val;
+            m2 = fmax(m2, cnorm2(tp));
+        }
+        if (idx < d2) m2 = fmax(m2, cnorm2(val));
+        else if (idx == d2) val = tail_prod();   // N > 2d: the tail sits inside the lower half
+        else val = cmake(0.0, 0.0);
+        x[i] = val;
+        x[R + i] = up;
+    }
+    fa_atomic_max_u64(&L.max2_out[P], dbits(m2));
+    // forward column step of the next level: length 2*N1, 2R points per lane
+    fft_wg<2 * N1, 2 * R, BC, -1, DB>(x, lds, v, c, G.tw1x2, parity);
+    cplx *dst = G.Y + (size_t)poly * (2 * N1) * N2;
+#pragma unroll
+    for (int i = 0; i < 2 * R; i++) {
+        const int k1 = v + (N1 / R) * i;   // (2N1)/(2R) = N1/R
+        dst[(size_t)k1 * N2 + n2] = x[i];  // twiddle applied by the next level's row kernel
+    }
 }
 
 // one lane per output matrix: turn the maxima of the large path into pending scales

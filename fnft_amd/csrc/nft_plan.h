@@ -121,9 +121,11 @@ public:
     size_t res_deg = 0;      // degree of the transfer matrix of the last tree run
     size_t start_n = 0, start_d = 0;  // matrices (all signals) / degree the tree run starts from
     bool use_leaf = true;    // fuse coefficients + first levels (nft_kernels.h body_leaf)
+    bool use_bridge = true;  // fuse inverse/forward column steps of consecutive split levels
     bool use_sym = true;     // NSE symmetry: store/transform only the first column (ne = 2)
     int ne = 4;              // stored entries per matrix in the current tree run
     int kappa_run = 1;
+    int dbg_flags = 0;       // timing ablation, set from FNFT_AMD_DBG by the HIP back end (diagnostics only)
 
     NftPlan(BE &be_, size_t D_, size_t M_, size_t batch_, int akns_disc_, int deg0_)
         : be(be_), D(D_), M(M_), batch(batch_), akns_disc(akns_disc_), deg0(deg0_)
@@ -304,6 +306,7 @@ public:
     {
         size_t n = start_n;     // matrices at the current level, all signals
         size_t d = start_d;
+        bool y_from_bridge = false;
         while (n / batch > 1) {
             TreeLevel L;
             L.body_in = body[cur]; L.tail_in = tail[cur]; L.scale_in = scale[cur];
@@ -317,6 +320,7 @@ public:
             L.pairs_per_signal = (int)(n / 2 / batch);
             L.ne = ne;
             L.kappa = kappa_run;
+            L.dbg = dbg_flags;
             const size_t N = nft_product_len(d);
             L.tw = (N <= (size_t)kMaxTwTable) ? tw_table(N) : nullptr;
             bool ok;
@@ -333,11 +337,20 @@ public:
                 G.btw = big_tw(N);
                 G.tw1 = (G.N1 >= 2) ? tw_table((size_t)G.N1) : nullptr;
                 G.tw2 = tw_table(kRowTree);
-                ok = dispatch_col_fwd(be, G);
+                G.tw1x2 = tw_table((size_t)2 * G.N1);
+                G.btw2 = big_tw(2 * N);
+                G.y_unscaled = y_from_bridge ? 1 : 0;
+                ok = true;
+                if (!y_from_bridge) ok = dispatch_col_fwd(be, G);
+                if (ok) run_mid(be, G);
+                // bridge straight into the next level's column step when that level is split too
+                const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= 256
+                                        && nft_product_len(2 * d) == 2 * N;
                 if (ok) {
-                    run_mid(be, G);
-                    ok = dispatch_col_inv(be, G);
+                    if (next_split) ok = dispatch_col_bridge(be, G);
+                    else ok = dispatch_col_inv(be, G);
                 }
+                y_from_bridge = ok && next_split;
                 if (ok) be.template run<KFinalizeScales>((int)((n / 2 + 63) / 64), 1, L);
             }
             if (!ok) return NFT_EC_NOT_YET_IMPLEMENTED;

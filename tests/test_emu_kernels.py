@@ -130,10 +130,12 @@ def test_chirpz_golden(emu, fixtures):
 
 
 @pytest.mark.parametrize("D,M,disc,kappa", [(256, 16, "2SPLIT2_MODAL", 1), (1000, 37, "2SPLIT4B", 1),
-                                             (300, 50, "2SPLIT3A", -1), (4097, 64, "2SPLIT4B", 1)])
+                                             (300, 50, "2SPLIT3A", -1), (4097, 64, "2SPLIT4B", 1),
+                                             (16384, 48, "2SPLIT2_MODAL", 1), (8192, 40, "2SPLIT3A", 1)])
 def test_nsev_vs_oracle(emu, oracle, D, M, disc, kappa):
-    """Whole pipeline in the emulator; D = 4097 with degree 2 reaches a split transform
-    (N = 16384 = 4 x 4096) in the top level of the tree."""
+    """Whole pipeline in the emulator; D = 4097 with degree 2 reaches a split transform in the
+    top level of the tree; D = 16384 (degree 1) and D = 8192 (degree 3, lengths that are not 2d)
+    have consecutive split levels joined by the bridge kernel."""
     T, XI = np.array([-25.0, 25.0]), np.array([-1.4, 1.6])
     q = S.sech_focusing(D, amp=3.2 if kappa == 1 else 1.1)
     out = np.zeros(3 * M, np.complex128)
