@@ -101,9 +101,15 @@ template <int N1> struct KColInv {
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
     static FA_DEV void body(const Params &p) { body_col_inv<N1, C::R, C::BC, C::DB>(p); }
 };
+#ifndef FA_BRIDGE_R
+#define FA_BRIDGE_R 16
+#endif
+#ifndef FA_BRIDGE_T
+#define FA_BRIDGE_T 256
+#endif
 template <int N1> struct BridgeCfg {
-    static constexpr int R = (N1 <= 16) ? N1 : 16;
-    static constexpr int THREADS = 256;
+    static constexpr int R = (N1 <= 16) ? N1 : FA_BRIDGE_R;
+    static constexpr int THREADS = (N1 <= 16) ? 256 : FA_BRIDGE_T;
     static constexpr int BC = THREADS / (N1 / R);
     static constexpr bool DB = false;
     static constexpr size_t lds_bytes() { return (N1 > R) ? (size_t)2 * N1 * BC * sizeof(cplx) : 0; }
