@@ -34,6 +34,9 @@ struct TreeLevel {
     cplx *tail_out;
     double *scale_out;
     unsigned long long *max2_out;  // per output matrix: bits of max |coef|^2 (large path)
+    const unsigned long long *max2_in;  // per input matrix, valid when in_pending
+    int in_pending;                // inputs come from a split level whose rescale is still pending:
+                                   // scale = 2^-a(max2_in), exponent = wexp_in + a(max2_in)
     const int *wexp_in;            // per input matrix: power-of-two exponent taken out so far
     int *wexp_out;                 // per output matrix: wexp_in[2P] + wexp_in[2P+1] + this level's
     size_t plane;                  // body plane stride, elements
@@ -71,6 +74,22 @@ FA_HD double bitsd(unsigned long long u)
     union { double d; unsigned long long u; } cv;
     cv.u = u;
     return cv.d;
+}
+
+FA_HD int exponent_of_max2(unsigned long long bits)
+{
+    const double m2 = bitsd(bits);
+    return (m2 > 0.0 && m2 < 1.0e300) ? half_exponent(m2) : 0;
+}
+// pending scale / accumulated exponent of input matrix `mat` of a level (see TreeLevel::in_pending)
+FA_DEV double level_in_scale(const TreeLevel &L, long long mat)
+{
+    if (!L.in_pending) return L.scale_in[mat];
+    return pow2i(-exponent_of_max2(L.max2_in[mat]));
+}
+FA_DEV int level_in_wexp(const TreeLevel &L, long long mat)
+{
+    return L.wexp_in[mat] + (L.in_pending ? exponent_of_max2(L.max2_in[mat]) : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -794,7 +813,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLeve
     const int poly = FA_BID_Y;
     const int e = poly / L.n_in, mat = poly % L.n_in;
     const int d = L.d, N2 = G.N2;
-    const double sc = L.scale_in[mat];
+    const double sc = level_in_scale(L, mat);
     const cplx *src = L.body_in + (size_t)e * L.plane + (size_t)mat * d;
     cplx x[R];
 #pragma unroll
@@ -829,8 +848,15 @@ template <int N2, int R> struct MidIO {
     {
         P = FA_BID / G.N1;
         k1 = FA_BID % G.N1;
-        sc[0] = G.y_unscaled ? G.L.scale_in[2 * P] : 1.0;
-        sc[1] = G.y_unscaled ? G.L.scale_in[2 * P + 1] : 1.0;
+        sc[0] = G.y_unscaled ? level_in_scale(G.L, 2 * P) : 1.0;
+        sc[1] = G.y_unscaled ? level_in_scale(G.L, 2 * P + 1) : 1.0;
+        // bookkeeping of the level, done once per pair before the column kernel that follows:
+        // exponent carried so far (this level's own is added by the consumer / the final
+        // finalize) and a clean slot for this level's maximum
+        if (k1 == 0 && FA_TID == 0) {
+            G.L.wexp_out[P] = level_in_wexp(G.L, 2 * P) + level_in_wexp(G.L, 2 * P + 1);
+            G.L.max2_out[P] = 0ull;
+        }
     }
     // w_N^{k1 n2} for element n2 = v + (N2/R)*i of this lane (same for every polynomial) =
     // per-lane look-up w^{k1 v} times the workgroup-uniform factor w^{k1 (N2/R) i}; formed per
@@ -918,7 +944,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
         cplx val = x[i] * inv;
         if (idx == 0) {
             // tails of the two factors -> constant term of the product, un-alias coefficient 0
-            const double sA = L.scale_in[2 * P], sB = L.scale_in[2 * P + 1];
+            const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
             TailSet t;
             cplx tp;
             if (L.ne == 4) {
@@ -991,7 +1017,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
     double m2 = 0.0;
     // constant term of the product (needed by the lanes holding index 0 and index 2d)
     auto tail_prod = [&]() -> cplx {
-        const double sA = L.scale_in[2 * P], sB = L.scale_in[2 * P + 1];
+        const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
         TailSet t;
         if (L.ne == 4) {
 #pragma unroll
@@ -1043,17 +1069,15 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
     }
 }
 
-// one lane per output matrix: turn the maxima of the large path into pending scales
+// one lane per output matrix of the LAST split level: turn its maxima into the pending scale and
+// add its exponent (intermediate split levels are finalized by their consumers, TreeLevel::in_pending)
 FA_DEV void body_finalize_scales(const TreeLevel &L)
 {
     const long long P = (long long)FA_BID * FA_BDIM + FA_TID;
     if (P >= L.n_in / 2) return;
-    const double m2 = bitsd(L.max2_out[P]);
-    int a = 0;
-    if (m2 > 0.0 && m2 < 1.0e300) a = half_exponent(m2);
+    const int a = exponent_of_max2(L.max2_out[P]);
     L.scale_out[P] = pow2i(-a);
-    L.max2_out[P] = 0ull;
-    L.wexp_out[P] = L.wexp_in[2 * P] + L.wexp_in[2 * P + 1] + a;
+    L.wexp_out[P] = L.wexp_out[P] + a;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -106,7 +106,7 @@ public:
     cplx *body[2] = {nullptr, nullptr};
     cplx *tail[2] = {nullptr, nullptr};
     double *scale[2] = {nullptr, nullptr};
-    unsigned long long *max2 = nullptr;
+    unsigned long long *max2[2] = {nullptr, nullptr};  // ping-pong across split levels
     int *wexp[2] = {nullptr, nullptr};  // per matrix, ping-pong with body/tail/scale
     int *status = nullptr;
     cplx *Y = nullptr, *Z = nullptr;
@@ -169,7 +169,7 @@ public:
             ok = ok && alloc(body[i], 4 * plane) && alloc(tail[i], 4 * n0) && alloc(scale[i], n0)
                  && alloc(wexp[i], n0);
         }
-        ok = ok && alloc(max2, n0) && alloc(status, 4);
+        ok = ok && alloc(max2[0], n0) && alloc(max2[1], n0) && alloc(status, 4);
         {   // scratch of the split transforms: 4*n_in polynomials of N forward, 4*n_out inverse,
             // maximised over the levels that use them (N can exceed 2d when d is not 2^k)
             size_t needY = 0, needZ = 0, n = n0, d = (size_t)deg0;
@@ -194,7 +194,6 @@ public:
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
         ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
         if (!ok) return NFT_EC_NOMEM;
-        be.memset0(max2, n0 * sizeof(unsigned long long));
         upload_twiddles();
         return NFT_SUCCESS;
     }
@@ -202,7 +201,7 @@ public:
     void destroy()
     {
         for (int i = 0; i < 2; i++) { be.free(body[i]); be.free(tail[i]); be.free(scale[i]); be.free(wexp[i]); }
-        be.free(max2); be.free(status); be.free(Y); be.free(Z);
+        be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z);
         be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
     }
 
@@ -307,11 +306,15 @@ public:
         size_t n = start_n;     // matrices at the current level, all signals
         size_t d = start_d;
         bool y_from_bridge = false;
+        bool in_pending = false;   // previous level was split: its rescale is still pending
+        int mcur = 0;
         while (n / batch > 1) {
             TreeLevel L;
             L.body_in = body[cur]; L.tail_in = tail[cur]; L.scale_in = scale[cur];
             L.body_out = body[cur ^ 1]; L.tail_out = tail[cur ^ 1]; L.scale_out = scale[cur ^ 1];
-            L.max2_out = max2;
+            L.max2_out = max2[mcur ^ 1];
+            L.max2_in = max2[mcur];
+            L.in_pending = in_pending ? 1 : 0;
             L.wexp_in = wexp[cur];
             L.wexp_out = wexp[cur ^ 1];
             L.plane = plane;
@@ -351,7 +354,11 @@ public:
                     else ok = dispatch_col_inv(be, G);
                 }
                 y_from_bridge = ok && next_split;
-                if (ok) be.template run<KFinalizeScales>((int)((n / 2 + 63) / 64), 1, L);
+                // the consumer of the next level finalizes this one; the last level needs a kernel
+                const bool last_level = (n / 2 / batch <= 1);
+                if (ok && last_level) be.template run<KFinalizeScales>((int)((n / 2 + 63) / 64), 1, L);
+                in_pending = !last_level;
+                mcur ^= 1;
             }
             if (!ok) return NFT_EC_NOT_YET_IMPLEMENTED;
             cur ^= 1;
