@@ -1173,11 +1173,27 @@ struct ChirpParams {
 };
 
 // exp((xr + i*xi)) with a real multiplier folded in: returns exp(t*lr) * cis(t*li)
+// exp(x) for the tiny exponents t*log|z| of numbers that are on the unit circle up to rounding
+FA_DEV double exp_small(double x)
+{
+    if (x == 0.0) return 1.0;
+    if (fabs(x) < 1.0e-5) return 1.0 + x * (1.0 + 0.5 * x);   // relative error < 2e-16
+    return exp(x);
+}
 FA_DEV cplx cpow_real(const double lg[2], double t)
 {
     double s, c;
     fa_sincos(t * lg[1], &s, &c);
-    const double mag = (lg[0] == 0.0) ? 1.0 : exp(t * lg[0]);
+    const double mag = exp_small(t * lg[0]);
+    return cmake(mag * c, mag * s);
+}
+// cpow(A, ta) * cpow(W, tw) with one sincos and one exp: the two exponents are added (one extra
+// rounding of the phase, < 1e-16 relative to its magnitude)
+FA_DEV cplx cpow_real2(const double la[2], double ta, const double lw[2], double tw)
+{
+    double s, c;
+    fa_sincos(fma(ta, la[1], tw * lw[1]), &s, &c);
+    const double mag = exp_small(fma(ta, la[0], tw * lw[0]));
     return cmake(mag * c, mag * s);
 }
 
@@ -1212,7 +1228,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_fwd(const C
         if (job < njobs) {
             if (n < Np) {  // :68-69  p[deg-n] * A^-n * W^(n^2/2)
                 const cplx pc = chirp_poly_coef(C, job / C.npoly, job % C.npoly, C.deg - n);
-                val = pc * cpow_real(C.logA, -dn) * cpow_real(C.logW, 0.5 * dn * dn);
+                val = pc * cpow_real2(C.logA, -dn, C.logW, 0.5 * dn * dn);
             }
         } else {  // :76-82
             if (n < C.M) val = cpow_real(C.logW, -0.5 * dn * dn);
@@ -1225,12 +1241,12 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_fwd(const C
     }
     int parity = 0;
     fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, C.tw1, parity);
+    // the twiddle w_L^{n2 k1} is applied by the row kernel (shared by all rows of one k1)
     cplx *dst = (job < njobs) ? C.Ybuf + (size_t)job * Lc : C.Vbuf;
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int k1 = v + (N1 / R) * i;
-        const cplx w = big_twiddle(C.btw, (unsigned)k1 * (unsigned)n2);
-        dst[(size_t)k1 * C.N2 + n2] = x[i] * w;
+        dst[(size_t)k1 * C.N2 + n2] = x[i];
     }
 }
 
@@ -1244,10 +1260,16 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
     const int k1 = FA_BID;
     const long long Lc = (long long)C.N1 * N2;
     int parity = 0;
+    // w_L^{k1 n2} for n2 = v + (N2/R) i: per-lane base times workgroup-uniform factors
+    const cplx base = big_twiddle(C.btw, (unsigned)k1 * (unsigned)v);
+    cplx tw[R];
+    tw[0] = base;
+#pragma unroll
+    for (int i = 1; i < R; i++) tw[i] = base * big_twiddle(C.btw, (unsigned)k1 * (unsigned)((N2 / R) * i));
     cplx vv[R];
     const cplx *vs = C.Vbuf + (size_t)k1 * N2;
 #pragma unroll
-    for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i];
+    for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i] * tw[i];
     fft_wg<N2, R, 1, -1, DB>(vv, lds, v, 0, C.tw2, parity);
     const int njobs = C.batch * C.npoly;
     const double inv = 1.0 / (double)N2;
@@ -1257,13 +1279,13 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
         cplx *ys = C.Ybuf + (size_t)job * Lc + (size_t)k1 * N2;
         cplx y[R];
 #pragma unroll
-        for (int i = 0; i < R; i++) y[i] = ys[v + (N2 / R) * i];
+        for (int i = 0; i < R; i++) y[i] = ys[v + (N2 / R) * i] * tw[i];
         fft_wg<N2, R, 1, -1, DB>(y, lds, v, 0, C.tw2, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) y[i] = y[i] * vv[i];
         fft_wg<N2, R, 1, +1, DB>(y, lds, v, 0, C.tw2, parity);
 #pragma unroll
-        for (int i = 0; i < R; i++) ys[v + (N2 / R) * i] = y[i] * inv;
+        for (int i = 0; i < R; i++) ys[v + (N2 / R) * i] = (y[i] * inv) * cconj(tw[i]);
     }
 }
 
@@ -1293,8 +1315,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const C
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const int k1 = v + (N1 / R) * i;
-            const cplx w = cconj(big_twiddle(C.btw, (unsigned)k1 * (unsigned)n2));
-            x[i] = src[(size_t)k1 * C.N2 + n2] * w;
+            x[i] = src[(size_t)k1 * C.N2 + n2];   // conj twiddle applied by the row kernel
         }
         fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, C.tw1, parity);
 #pragma unroll
@@ -1302,10 +1323,9 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const C
             const int n1 = v + (N1 / R) * i;
             const long long m = (long long)n1 * C.N2 + n2;
             const double dm = (double)m;
-            // :94-95  W^(m^2/2) * V[m] / L   (1/N2 was applied by the row step)
-            cplx h = cmake(0.0, 0.0);
-            if (m < C.M) h = (x[i] * inv) * cpow_real(C.logW, 0.5 * dm * dm);
-            H[slot][i] = h;
+            // V[m] / L here (1/N2 was applied by the row step); W^(m^2/2) follows below, once
+            (void)dm;
+            H[slot][i] = (m < C.M) ? x[i] * inv : cmake(0.0, 0.0);
         }
     }
 #pragma unroll
@@ -1313,6 +1333,12 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const C
         const int n1 = v + (N1 / R) * i;
         const long long m = (long long)n1 * C.N2 + n2;
         if (m >= C.M) continue;
+        {   // :94-95  result[m] = W^(m^2/2) * V[m] / L
+            const double dm = (double)m;
+            const cplx cw = cpow_real(C.logW, 0.5 * dm * dm);
+            H[0][i] = H[0][i] * cw;
+            H[1][i] = H[1][i] * cw;
+        }
         if (C.cstype < 0) {  // raw chirp-z values
 #pragma unroll
             for (int slot = 0; slot < 2; slot++)
