@@ -24,6 +24,18 @@
 #define FA_LDS_PTR (fa_lds_raw)
 FA_DEV void fa_atomic_max_u64(unsigned long long *p, unsigned long long v) { atomicMax(p, v); }
 FA_DEV void fa_atomic_add_i32(int *p, int v) { atomicAdd(p, v); }
+// max over the 64 lanes of the wave, then ONE atomic per wave (do not rely on the compiler's
+// atomic optimizer: without the reduction 2^20 lanes hit a handful of addresses)
+FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+        union { double d; unsigned long long u; } cv;
+        cv.d = v;
+        atomicMax(p, cv.u);
+    }
+}
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 #else
@@ -54,6 +66,12 @@ FA_DEV void fa_atomic_max_u64(unsigned long long *p, unsigned long long v)
     while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 FA_DEV void fa_atomic_add_i32(int *p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
+{
+    union { double d; unsigned long long u; } cv;
+    cv.d = v;
+    fa_atomic_max_u64(p, cv.u);
+}
 FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
 using std::exp;

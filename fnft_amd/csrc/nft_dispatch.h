@@ -121,6 +121,13 @@ template <int N1> struct KColBridge {
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
     static FA_DEV void body(const Params &p) { body_col_bridge<N1, C::R, C::BC, C::DB>(p); }
 };
+template <int N1> struct KColBridge2 {   // spectral doubling: same tiling as the plain column steps
+    using Params = BigLevel;
+    using C = ColCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_col_bridge2<N1, C::R, C::BC, C::DB>(p); }
+};
 template <int NE> struct KMid {
     using Params = BigLevel;
     static constexpr int R = 8;
@@ -261,6 +268,16 @@ template <class BE> bool dispatch_col_bridge(BE &be, const BigLevel &G)
     const int polys = G.L.ne * (G.L.n_in / 2);
     switch (G.N1) {
 #define X(n1) case n1: be.template run<KColBridge<n1>>(G.N2 / BridgeCfg<n1>::BC, polys, G); return true;
+        FA_FOR_EACH_BRIDGE_N1(X)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_col_bridge2(BE &be, const BigLevel &G)
+{
+    const int polys = G.L.ne * (G.L.n_in / 2);
+    switch (G.N1) {
+#define X(n1) case n1: be.template run<KColBridge2<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
         FA_FOR_EACH_BRIDGE_N1(X)
 #undef X
     default: return false;

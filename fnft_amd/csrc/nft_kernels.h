@@ -798,6 +798,11 @@ struct BigLevel {
     const cplx *tw1x2;
     BigTwiddle btw2;
     int y_unscaled;  // row kernel multiplies by scale_in on load
+    // spectral doubling (body_col_bridge2): Y holds only the ODD rows k1 = 2j+1 of the next
+    // level's column transform ([poly][j][n2]); the EVEN rows k1 = 2j are the previous level's Z
+    // rows j, read in place from Zprev
+    const cplx *Zprev;
+    int y_split;
 };
 
 // column step of the forward transform of every input polynomial of the level
@@ -868,7 +873,14 @@ template <int N2, int R> struct MidIO {
     FA_DEV void load(int which, int e, cplx (&x)[R], int v, int)
     {
         const int n_in = G.L.n_in;
-        const cplx *src = G.Y + ((size_t)((size_t)e * n_in + 2 * P + which) * G.N1 + k1) * N2;
+        const size_t pi = (size_t)e * n_in + 2 * P + which;
+        const cplx *src;
+        if (G.y_split) {
+            const cplx *half = (k1 & 1) ? G.Y : G.Zprev;
+            src = half + (pi * (size_t)(G.N1 / 2) + (size_t)(k1 >> 1)) * N2;
+        } else {
+            src = G.Y + (pi * (size_t)G.N1 + k1) * N2;
+        }
         const cplx base = big_twiddle(G.btw, (unsigned)k1 * (unsigned)v) * sc[which];
 #pragma unroll
         for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i] * twiddle(base, i);
@@ -972,7 +984,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
             m2 = fmax(m2, cnorm2(val));
         }
     }
-    fa_atomic_max_u64(&L.max2_out[P], dbits(m2));
+    fa_wave_atomic_max_f64bits(&L.max2_out[P], m2);   // P is uniform in the workgroup
 }
 
 // Bridge between two consecutive split levels: inverse column step of level l (N = N1*N2)
@@ -1058,7 +1070,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
         x[i] = val;
         x[R + i] = up;
     }
-    fa_atomic_max_u64(&L.max2_out[P], dbits(m2));
+    fa_wave_atomic_max_f64bits(&L.max2_out[P], m2);   // P is uniform in the workgroup
     // forward column step of the next level: length 2*N1, 2R points per lane
     fft_wg<2 * N1, 2 * R, BC, -1, DB>(x, lds, v, c, G.tw1x2, parity);
     cplx *dst = G.Y + (size_t)poly * (2 * N1) * N2;
@@ -1066,6 +1078,105 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
     for (int i = 0; i < 2 * R; i++) {
         const int k1 = v + (N1 / R) * i;   // (2N1)/(2R) = N1/R
         dst[(size_t)k1 * N2 + n2] = x[i];  // twiddle applied by the next level's row kernel
+    }
+}
+
+// Bridge with spectral doubling (N = 2d only).  The next level's column transform of length 2*N1
+// of a column whose upper half is zero has, exactly,
+//     even rows  Y'[2j]   = this level's Z row j                     (nothing to compute or move),
+//     odd rows   Y'[2j+1] = DFT_N1( x[n1] * w_{2N1}^{n1} )[j]  (- t for column 0, t = product tail),
+// where x = IDFT_N1(z)/N1 are the coefficients (with the alias fix x[0] -= t in column 0).  So the
+// bridge is one inverse and one forward transform of length N1, R points per lane, and writes
+// only the odd rows; the row kernel of the next level reads the even rows from Z in place.
+template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const BigLevel &G)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int poly = FA_BID_Y;
+    const int n_out = L.n_in / 2;
+    const int e = poly / n_out, P = poly % n_out;
+    const int N2 = G.N2;
+    const int d2 = 2 * L.d;
+    const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    cplx x[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) x[i] = src[(size_t)(v + (N1 / R) * i) * N2 + n2];
+    int parity = 0;
+    fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, G.tw1, parity);
+    const double inv = 1.0 / (double)N1;
+    double m2 = 0.0;
+    cplx tp = cmake(0.0, 0.0);
+    if (n2 == 0 && v == 0) {   // the lane that holds index 0
+        const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
+        TailSet t;
+        if (L.ne == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+                t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+            }
+            tp = tail_product_general(t, e);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+                t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+                t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
+            }
+            tp = tail_product_sym(t, e, L.kappa);
+        }
+        L.tail_out[(size_t)e * n_out + P] = tp;
+        m2 = cnorm2(tp);
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n1 = v + (N1 / R) * i;
+        cplx val = x[i] * inv;
+        if (n1 == 0 && n2 == 0) {
+            val = val - tp;   // un-alias coefficient 2d folded onto 0
+            L.body_out[(size_t)e * L.plane + (size_t)P * d2] = val;   // the next level's "lead"
+        }
+        m2 = fmax(m2, cnorm2(val));
+        x[i] = val * G.tw1x2[n1];   // * w_{2N1}^{n1}
+    }
+    fa_wave_atomic_max_f64bits(&L.max2_out[P], m2);   // P is uniform in the workgroup
+    fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, G.tw1, parity);
+    cplx *dst = G.Y + (size_t)poly * N1 * N2;   // odd rows only: [poly][j][n2]
+    // column 0: the tail at index N contributes t * w_{2N1}^{N1 (2j+1)} = -t to every odd row
+    const bool col0 = (n2 == 0);
+    cplx tpc = cmake(0.0, 0.0);
+    if (col0) {
+        // every lane of column 0 needs t: recompute it (cheap, uniform within the few lanes)
+        if (v == 0) tpc = tp;
+        else {
+            const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
+            TailSet t;
+            if (L.ne == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+                }
+                tpc = tail_product_general(t, e);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+                    t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
+                }
+                tpc = tail_product_sym(t, e, L.kappa);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int j = v + (N1 / R) * i;
+        dst[(size_t)j * N2 + n2] = x[i] - tpc;
     }
 }
 

@@ -109,7 +109,7 @@ public:
     unsigned long long *max2[2] = {nullptr, nullptr};  // ping-pong across split levels
     int *wexp[2] = {nullptr, nullptr};  // per matrix, ping-pong with body/tail/scale
     int *status = nullptr;
-    cplx *Y = nullptr, *Z = nullptr;
+    cplx *Y = nullptr, *Z = nullptr, *Z2 = nullptr;   // Z ping-pongs when spectral doubling is on
     cplx *chY = nullptr, *chV = nullptr, *chH = nullptr;
     cplx *tm_out = nullptr;
     cplx *twtab = nullptr;   // concatenated tables for N = 2,4,...,kMaxTwTable
@@ -122,6 +122,7 @@ public:
     size_t start_n = 0, start_d = 0;  // matrices (all signals) / degree the tree run starts from
     bool use_leaf = true;    // fuse coefficients + first levels (nft_kernels.h body_leaf)
     bool use_bridge = true;  // fuse inverse/forward column steps of consecutive split levels
+    bool use_doubling = true; // ... with spectral doubling when N = 2d (body_col_bridge2)
     bool use_sym = true;     // NSE symmetry: store/transform only the first column (ne = 2)
     int ne = 4;              // stored entries per matrix in the current tree run
     int kappa_run = 1;
@@ -182,7 +183,7 @@ public:
                 n /= 2;
                 d *= 2;
             }
-            if (needY) ok = ok && alloc(Y, needY) && alloc(Z, needZ);
+            if (needY) ok = ok && alloc(Y, needY) && alloc(Z, needZ) && alloc(Z2, needZ);
         }
         if (M > 0) {
             const size_t Np = D * (size_t)deg0 + 1;
@@ -201,7 +202,7 @@ public:
     void destroy()
     {
         for (int i = 0; i < 2; i++) { be.free(body[i]); be.free(tail[i]); be.free(scale[i]); be.free(wexp[i]); }
-        be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z);
+        be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
         be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
     }
 
@@ -306,6 +307,8 @@ public:
         size_t n = start_n;     // matrices at the current level, all signals
         size_t d = start_d;
         bool y_from_bridge = false;
+        bool y_split = false;      // Y holds odd rows only, even rows are the previous Z
+        int zcur = 0;
         bool in_pending = false;   // previous level was split: its rescale is still pending
         int mcur = 0;
         while (n / batch > 1) {
@@ -334,7 +337,10 @@ public:
             } else {
                 BigLevel G;
                 G.L = L;
-                G.Y = Y; G.Z = Z;
+                G.Y = Y;
+                G.Z = zcur ? Z2 : Z;
+                G.Zprev = zcur ? Z : Z2;
+                G.y_split = y_split ? 1 : 0;
                 G.N2 = kRowTree;
                 G.N1 = (int)(N / kRowTree);
                 G.btw = big_tw(N);
@@ -349,10 +355,14 @@ public:
                 // bridge straight into the next level's column step when that level is split too
                 const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= 256
                                         && nft_product_len(2 * d) == 2 * N;
+                const bool doubling = next_split && use_doubling && N == 2 * d;
                 if (ok) {
-                    if (next_split) ok = dispatch_col_bridge(be, G);
+                    if (doubling) ok = dispatch_col_bridge2(be, G);
+                    else if (next_split) ok = dispatch_col_bridge(be, G);
                     else ok = dispatch_col_inv(be, G);
                 }
+                y_split = ok && doubling;
+                zcur ^= 1;
                 y_from_bridge = ok && next_split;
                 // the consumer of the next level finalizes this one; the last level needs a kernel
                 const bool last_level = (n / 2 / batch <= 1);
