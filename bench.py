@@ -110,7 +110,6 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    tree_ms_sum = 0.0
     for i in range(args.steps):
         one_step(i, pending)
     for w in pending:
@@ -147,9 +146,16 @@ def main():
         t_tree = float(np.median(tms))
         bt = bytes_tree(D, deg0)
         achieved = bt / (t_tree * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_tree_traffic.json")
+        if os.path.exists(tpath) and args.log2D == 20 and args.disc == "2SPLIT2_MODAL":
+            # measured HBM bytes of the same launches (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate passes, FETCH doubled as the microarch guide prescribes); see profiles/
+            with open(tpath) as f:
+                traffic = json.load(f)["tree_hbm_bytes_per_transform"]
         roof = {"bound": "hbm", "kernel": "poly_fmult2x2 tree (coefficients + all level launches of one transform)",
                 "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
                 "chirpz_epilogue_ms": round(float(chirp_ms), 4)}
         if not args.no_cpu_baseline:
