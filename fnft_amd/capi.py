@@ -166,7 +166,8 @@ def default_opts():
 # host-pointer calls (drop-in boundary)
 # --------------------------------------------------------------------------------------------
 def fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="REFLECTION_COEFFICIENT",
-              normalization_flag=1, opts=None, want_contspec=True, bound_states=None, K=None):
+              normalization_flag=1, opts=None, want_contspec=True, bound_states=None, K=None,
+              richardson=False):
     """fnft_nsev() through the C ABI with host (numpy) buffers.  Returns (rc, contspec)."""
     L = load()
     q = _c128(q)
@@ -175,6 +176,7 @@ def fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="RE
         opts.discretization = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
         opts.contspec_type = CSTYPE[contspec_type] if isinstance(contspec_type, str) else int(contspec_type)
         opts.normalization_flag = int(normalization_flag)
+        opts.richardson_extrapolation_flag = 1 if richardson else 0
     Tn = None if T is None else np.ascontiguousarray(T, np.float64)
     XIn = None if XI is None else np.ascontiguousarray(XI, np.float64)
     fac = CS_FACTOR.get(int(opts.contspec_type), 3)

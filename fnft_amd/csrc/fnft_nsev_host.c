@@ -6,6 +6,7 @@
  * the numerical work to the HIP shim (hip_backend.hip).  There is no CPU fallback: without a
  * usable GPU the call fails with FNFT_EC_OTHER and an error message.
  */
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -184,8 +185,6 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
     }
     if (kappa == +1 && bound_states != NULL)
         return E_NOT_YET_IMPLEMENTED(bound_states, "Pass bound_states = NULL for the continuous spectrum.");
-    if (opts->richardson_extrapolation_flag == 1)
-        return E_NOT_YET_IMPLEMENTED(richardson_extrapolation_flag, "Richardson extrapolation.");
     if (contspec != NULL && M > 0) {
         const int cst = (int)opts->contspec_type;
         if (cst < 0 || cst > 2) { /* src/fnft_nsev.c:880-883, raised inside nsev_compute_contspec */
@@ -202,6 +201,50 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
         if (ret_code == FNFT_EC_OTHER || ret_code == FNFT_EC_NOMEM)
             return raise(ret_code, __func__, __LINE__, "GPU runtime failure (see fnft_amd_last_error()).");
         return E_SUBROUTINE(ret_code);
+    }
+
+    /* Richardson extrapolation of the continuous spectrum, src/fnft_nsev.c:316-406: second
+     * transform of every other sample (subsampling rule of
+     * src/private/fnft__nse_discretization.c:426-473), method order 2 for all 2SPLIT schemes
+     * (src/private/fnft__akns_discretization.c:157-192). */
+    if (opts->richardson_extrapolation_flag == 1 && contspec != NULL && M > 0) {
+        const FNFT_REAL eps_t = (T[1] - T[0]) / (D - 1);
+        const int cst = (int)opts->contspec_type;
+        const FNFT_UINT cs_len = M * (cst == 0 ? 1 : (cst == 1 ? 2 : 3));
+        FNFT_UINT Dsub = D / 2; /* CEIL(D/2) on integers, :376 */
+        if (Dsub < 2) Dsub = 2;
+        if (Dsub > D) Dsub = D;
+        const FNFT_UINT nskip = (FNFT_UINT)round((FNFT_REAL)D / Dsub);
+        Dsub = (FNFT_UINT)round((FNFT_REAL)D / nskip);
+        FNFT_COMPLEX *qsub = malloc(Dsub * sizeof(FNFT_COMPLEX));
+        FNFT_COMPLEX *csub = malloc(cs_len * sizeof(FNFT_COMPLEX));
+        if (qsub == NULL || csub == NULL) {
+            free(qsub);
+            free(csub);
+            return raise(FNFT_EC_NOMEM, __func__, __LINE__, "Out of memory.");
+        }
+        for (FNFT_UINT i = 0; i < Dsub; i++) qsub[i] = q[i * nskip];
+        const FNFT_REAL Tsub[2] = {T[0], T[0] + ((Dsub - 1) * nskip) * eps_t};
+        const FNFT_REAL eps_t_sub = (Tsub[1] - Tsub[0]) / (Dsub - 1);
+        ret_code = fnft_amd__nsev_contspec_host(Dsub, qsub, Tsub, M, csub, XI, kappa,
+                                                (int)opts->discretization, cst, opts->normalization_flag);
+        if (ret_code == FNFT_SUCCESS) {
+            const FNFT_REAL scl_num = pow(eps_t_sub / eps_t, 2.0);
+            const FNFT_REAL scl_den = scl_num - 1.0;
+            const FNFT_REAL dxi = (XI[1] - XI[0]) / (M - 1);
+            const FNFT_REAL pi = acos(-1.0);
+            for (FNFT_UINT i = 0; i < M; i++)
+                if (fabs(XI[0] + dxi * i) < 0.9 * pi / (2.0 * eps_t_sub))
+                    for (FNFT_UINT j = 0; j < cs_len; j += M)
+                        contspec[i + j] = (scl_num * contspec[i + j] - csub[i + j]) / scl_den;
+        }
+        free(qsub);
+        free(csub);
+        if (ret_code != FNFT_SUCCESS) {
+            if (ret_code == FNFT_EC_OTHER || ret_code == FNFT_EC_NOMEM)
+                return raise(ret_code, __func__, __LINE__, "GPU runtime failure (see fnft_amd_last_error()).");
+            return E_SUBROUTINE(ret_code);
+        }
     }
     /* src/fnft_nsev.c:558-560: no discrete spectrum was computed */
     if (K_ptr != NULL) *K_ptr = 0;

@@ -645,9 +645,55 @@ int orc_nsev_contspec(size_t deg, int32_t W, const orc_cplx *tm, const double *T
     return ORC_SUCCESS;
 }
 
-/* fnft_nsev.c:133-453 + 458-565, contspec-only subset (see header) */
+/* fnft_nsev.c:458-565 (fnft_nsev_base), contspec-only subset */
+static int orc_nsev_base(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
+                         const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag);
+
+/* fnft_nsev.c:133-453, contspec-only subset, with Richardson extrapolation (:316-406): a second
+ * transform of every other sample (fnft__nse_discretization.c:426-473 subsampling rule) and
+ * (s*fine - coarse)/(s - 1), s = (eps_sub/eps)^order, order 2 for every 2SPLIT scheme
+ * (fnft__akns_discretization.c:157-192), on the grid points with |xi| < 0.9*pi/(2*eps_sub). */
+int orc_fnft_nsev_ex(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
+                     const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag,
+                     int richardson_flag)
+{
+    int rc = orc_nsev_base(D, q, T, M, contspec, XI, kappa, nse_disc, cstype, normalization_flag);
+    if (rc != ORC_SUCCESS || !richardson_flag || !contspec || M == 0) return rc;
+    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
+    size_t Dsub = D / 2; /* CEIL(D/2) on integers, fnft_nsev.c:376 */
+    if (Dsub < 2) Dsub = 2;
+    if (Dsub > D) Dsub = D;
+    const size_t nskip = (size_t)round((double)D / (double)Dsub);
+    Dsub = (size_t)round((double)D / (double)nskip);
+    const size_t cs_len = M * (cstype == ORC_CS_RHO ? 1 : (cstype == ORC_CS_AB ? 2 : 3));
+    orc_cplx *qsub = malloc(Dsub * sizeof(orc_cplx)), *csub = malloc(cs_len * sizeof(orc_cplx));
+    if (!qsub || !csub) { free(qsub); free(csub); return ORC_EC_NOMEM; }
+    for (size_t i = 0; i < Dsub; i++) qsub[i] = q[i * nskip];
+    const double Tsub[2] = {T[0], T[0] + (double)((Dsub - 1) * nskip) * eps_t};
+    const double eps_sub = (Tsub[1] - Tsub[0]) / (double)(Dsub - 1);
+    rc = orc_nsev_base(Dsub, qsub, Tsub, M, csub, XI, kappa, nse_disc, cstype, normalization_flag);
+    if (rc == ORC_SUCCESS) {
+        const double scl_num = pow(eps_sub / eps_t, 2.0), scl_den = scl_num - 1.0;
+        const double dxi = (XI[1] - XI[0]) / (double)(M - 1);
+        const double pi = acos(-1.0);
+        for (size_t i = 0; i < M; i++)
+            if (fabs(XI[0] + dxi * (double)i) < 0.9 * pi / (2.0 * eps_sub))
+                for (size_t j = 0; j < cs_len; j += M)
+                    contspec[i + j] = (scl_num * contspec[i + j] - csub[i + j]) / scl_den;
+    }
+    free(qsub);
+    free(csub);
+    return rc;
+}
+
 int orc_fnft_nsev(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
                   const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag)
+{
+    return orc_nsev_base(D, q, T, M, contspec, XI, kappa, nse_disc, cstype, normalization_flag);
+}
+
+static int orc_nsev_base(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
+                         const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag)
 {
     if (D < 2 || !q || !T || !(T[0] < T[1])) return ORC_EC_INVALID_ARGUMENT;
     if (contspec && (!XI || !(XI[0] < XI[1]))) return ORC_EC_INVALID_ARGUMENT;

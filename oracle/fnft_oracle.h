@@ -106,6 +106,11 @@ int orc_fnft_nsev(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cp
                   const double *XI, int kappa, int nse_disc, int contspec_type,
                   int normalization_flag);
 
+/* same with Richardson extrapolation of the continuous spectrum (fnft_nsev.c:316-406) */
+int orc_fnft_nsev_ex(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
+                     const double *XI, int kappa, int nse_disc, int contspec_type,
+                     int normalization_flag, int richardson_flag);
+
 /* wall-clock seconds spent in the last orc_fnft_nsev call: [0] fscatter, [1] contspec */
 void orc_last_timings(double out[2]);
 

@@ -71,6 +71,8 @@ class Oracle:
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.c_int]
         L.orc_fnft_nsev.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_fnft_nsev_ex.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_last_timings.argtypes = [C.c_double * 2]
         L.orc_last_timings.restype = None
 
@@ -158,7 +160,8 @@ class Oracle:
         dd = d.value
         return rc, dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
 
-    def fnft_nsev(self, q, T, M, XI, kappa=1, disc="2SPLIT4B", cstype="BOTH", normalize=True):
+    def fnft_nsev(self, q, T, M, XI, kappa=1, disc="2SPLIT4B", cstype="BOTH", normalize=True,
+                  richardson=False):
         """Continuous spectrum only.  Returns (rc, contspec) with contspec of length M*{1,2,3}."""
         q = _c128(q)
         T = np.ascontiguousarray(T, np.float64)
@@ -166,8 +169,8 @@ class Oracle:
         n = NSE_DISC[disc] if isinstance(disc, str) else int(disc)
         c = CSTYPE[cstype] if isinstance(cstype, str) else int(cstype)
         out = np.zeros(M * {0: 1, 1: 2, 2: 3}[c], np.complex128)
-        rc = self.lib.orc_fnft_nsev(q.size, _ptr(q), _ptr(T), M, _ptr(out), _ptr(XI), kappa, n, c,
-                                    1 if normalize else 0)
+        rc = self.lib.orc_fnft_nsev_ex(q.size, _ptr(q), _ptr(T), M, _ptr(out), _ptr(XI), kappa, n, c,
+                                       1 if normalize else 0, 1 if richardson else 0)
         return rc, out
 
     def last_timings(self):

@@ -178,7 +178,14 @@ def main():
                 targets = range(len(vals2)) if not idx.isdigit() else [int(idx)]
                 for t in targets:
                     vals2[t] = vals2[t] * fac if sign == "*" else vals2[t] / fac
+        # Richardson stage (present in some files): error_bounds_RE at D, then /16 (4th order) at 2D
+        vals_re = None
+        mre = re.search(r"error_bounds_RE\s*\[\s*6\s*\]\s*=\s*\{(.*?)\}\s*;", src, flags=re.S)
+        if mre:
+            vals_re = [float(eval(x.strip(), {"__builtins__": {}, "float": float, "INFINITY": float("inf")}, {}))
+                       for x in mre.group(1).split(",") if x.strip()]
         bounds.append({
+            "error_bounds_RE": vals_re[:3] if vals_re else None,
             "file": fn, "testcase": mtc.group(1),
             "discretization": mdisc.group(1) if mdisc else "2SPLIT4B",
             "D": int(mD.group(1)), "error_bounds": vals[:3],

@@ -95,8 +95,8 @@ def test_unknown_and_unsupported_options(capi):
     o.discretization = capi.NSE_DISC["2SPLIT8B"]
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     o = capi.default_opts()
-    o.richardson_extrapolation_flag = 1
-    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    o.richardson_extrapolation_flag = 1                                           # accepted; needs the GPU
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_OTHER
     # discrete spectrum requested
     bs = np.zeros(16, np.complex128)
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], bound_states=bs, K=16)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED

@@ -202,6 +202,49 @@ def test_fnft_nsev_analytic_bounds(capi, fixtures, b):
             assert e <= bound, (D, errs, bounds)
 
 
+@pytest.mark.parametrize("testcase,kappa", [("SECH_FOCUSING", 1), ("SECH_DEFOCUSING", -1)])
+def test_fnft_nsev_richardson(capi, oracle, fixtures, testcase, kappa):
+    """richardson_extrapolation_flag = 1 (src/fnft_nsev.c:316-406) against the bounds of
+    test/fnft_nsev/fnft_nsev_test_sech_{focusing,defocusing}_2split4A.c (error_bounds_RE at D = 4096,
+    /16 at 2D) and against the oracle's restatement of the same combination."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_fixtures.json")) as f:
+        allb = json.load(f)["nsev_error_bounds"]
+    b = [x for x in allb if x["discretization"] == "2SPLIT4A" and x["testcase"] == testcase
+         and x.get("error_bounds_RE")][0]
+    fx = fixtures["nsev_sech_focusing" if kappa == 1 else "nsev_sech_defocusing"]
+    M = fx["M"]
+    sig = S.sech_focusing if kappa == 1 else S.sech_defocusing
+    exact_rho = S.l2c(fx["contspec"])
+    exact_ab = S.l2c(fx["ab"]) if kappa == 1 else None
+    for D, scl in ((b["D"], 1.0), (2 * b["D"], 1.0 / 16.0), (b["D"] + 1, None), (3001, None)):
+        q = sig(D)
+        rc, cs = capi.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, discretization="2SPLIT4A",
+                                contspec_type="BOTH", richardson=True)
+        assert rc == 0, capi.last_error()
+        rc2, ref = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, disc="2SPLIT4A", cstype="BOTH",
+                                    richardson=True)
+        assert rc2 == 0
+        for j in range(3):
+            assert S.rel_err(cs[j * M:(j + 1) * M], ref[j * M:(j + 1) * M]) < 1e-11, (D, j)
+        if scl is not None:
+            errs = [S.rel_err(cs[:M], exact_rho)]
+            if exact_ab is not None:
+                errs += [S.rel_err(cs[M:2 * M], exact_ab[:M]), S.rel_err(cs[2 * M:], exact_ab[M:])]
+            for e, bound in zip(errs, b["error_bounds_RE"]):
+                if np.isfinite(bound):
+                    assert e <= bound * scl, (D, errs, b["error_bounds_RE"])
+    # reflection-only layout goes through the same combination loop
+    q = sig(512)
+    rc, cs = capi.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, discretization="2SPLIT2A",
+                            contspec_type="REFLECTION_COEFFICIENT", richardson=True)
+    rc2, ref = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, disc="2SPLIT2A", cstype="RHO",
+                                richardson=True)
+    assert rc == 0 and rc2 == 0 and S.rel_err(cs, ref) < 1e-11
+
+
 # ---- BASELINE.json full size: properties that do not need a CPU run of that size ---------------
 @pytest.mark.parametrize("disc,order_bound,floor", [("2SPLIT2_MODAL", 5.0e-3, 2e-9), ("2SPLIT4B", 3.9e-6, 2e-8)])
 def test_full_size_2p20_analytic(capi, disc, order_bound, floor):

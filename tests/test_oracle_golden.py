@@ -88,7 +88,7 @@ def test_akns_fscatter_golden(oracle, fixtures, scheme, normalize):
     assert S.rel_err(vals, S.l2c(fx["result_exact"])) <= fixtures["akns_fscatter"]["tol_rel_l1"]
 
 
-def _nsev_errors(oracle, fixtures, testcase, disc, D):
+def _nsev_errors(oracle, fixtures, testcase, disc, D, richardson=False):
     if testcase == "SECH_FOCUSING":
         fx = fixtures["nsev_sech_focusing"]
         q = S.sech_focusing(D)
@@ -105,7 +105,8 @@ def _nsev_errors(oracle, fixtures, testcase, disc, D):
         exact_rho = S.truncated_soliton_contspec(fx["XI"], fx["M"])
         exact_ab = None
     M = fx["M"]
-    rc, cs = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=fx["kappa"], disc=disc, cstype="BOTH")
+    rc, cs = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=fx["kappa"], disc=disc, cstype="BOTH",
+                              richardson=richardson)
     assert rc == 0
     errs = [S.rel_err(cs[:M], exact_rho)]
     if exact_ab is not None:
@@ -140,6 +141,26 @@ def test_fnft_nsev_analytic_bounds(oracle, fixtures, b):
         for e, bound in zip(errs, bounds):
             if np.isfinite(bound):
                 assert e <= bound, (DD, errs, b)
+
+
+def _re_cases():
+    return [c for c in _bound_cases() if c.values[0].get("error_bounds_RE")]
+
+
+@pytest.mark.parametrize("b", _re_cases())
+def test_fnft_nsev_richardson_bounds(oracle, fixtures, b):
+    """test/fnft_nsev/fnft_nsev_test_sech_*_2split4A.c: richardson_extrapolation_flag = 1 with
+    error_bounds_RE at D and error_bounds_RE/16 at 2D (fourth order after extrapolation)."""
+    D = b["D"]
+    for DD, scl in ((D, 1.0), (2 * D, 1.0 / 16.0)):
+        errs = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], DD, richardson=True)
+        for e, bound in zip(errs, b["error_bounds_RE"]):
+            if np.isfinite(bound):
+                assert e <= bound * scl, (DD, errs, b)
+    # and the extrapolation actually changes (improves) the plain result
+    plain = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], D)
+    rich = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], D, richardson=True)
+    assert rich[0] < plain[0]
 
 
 def test_modal_defocusing_step_check(oracle):
