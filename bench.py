@@ -9,6 +9,9 @@ tree -> chirp z-transform -> a, b, rho) over one synthetic signal of BASELINE.js
 D = M = 2^20 complex128 samples, q = 3.2i*sech(t), T = [-25, 25], XI = [-7/5, 8/5],
 2SPLIT2_MODAL, contspec_type BOTH, normalisation on.  Inputs and outputs are resident in HBM.
 
+`--workload cfg3` runs BASELINE.json configs[2] instead (512 independent signals of D = M = 2^16 over 8
+GPUs = 64 signals per GPU in one batched plan, XI = [-4, 4]); the default is the headline configs[1].
+
 With N ranks every rank transforms its own signal (weak scaling, no data-path collective) and
 the result shards are gathered on rank 0 with one RCCL gather per step, overlapped with the next
 step's compute on RCCL's stream.  Rank 0 prints ONE JSON line.
@@ -40,8 +43,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2D", type=int, default=20)
     ap.add_argument("--disc", default="2SPLIT2_MODAL")
+    ap.add_argument("--workload", choices=("cfg2", "cfg3"), default="cfg2",
+                    help="cfg2: one signal D=M=2^20 per GPU (headline); cfg3: BASELINE.json configs[2], "
+                         "64 of the 512 signals D=M=2^16 per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N>1 control-flow rehearsal on a box with fewer GPUs than ranks: gloo backend, "
+                         "host-staged gather, ranks share the visible GPUs (not a measurement)")
     args = ap.parse_args()
 
     import torch
@@ -54,24 +63,39 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.rehearse_gloo:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    cfg3 = args.workload == "cfg3"
+    if cfg3:
+        args.log2D = 16
     D = M = 1 << args.log2D
+    B = 64 if cfg3 else 1   # signals per GPU
     deg0 = {"2SPLIT2_MODAL": 1, "2SPLIT4B": 2}.get(args.disc, 1)
-    T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
-    # each rank gets its own (slightly different) signal so that no rank can reuse another's work
-    q_host = S.sech_focusing(D, amp=3.2 - 0.01 * rank)
+    T = [-25.0, 25.0]
+    XI = [-4.0, 4.0] if cfg3 else [-7.0 / 5.0, 8.0 / 5.0]
+    if cfg3:
+        # SURVEY 8d cfg 3: signal k = A*sech(t - tau)*exp(i*w*t), (A, tau, w) from splitmix64(0x5EED0000+k)
+        q_host = np.stack([S.batch_signal(rank * B + k, D, T) for k in range(B)])
+    else:
+        # each rank gets its own (slightly different) signal so that no rank can reuse another's work
+        q_host = S.sech_focusing(D, amp=3.2 - 0.01 * rank)
 
-    plan = capi.Plan(D, M, batch=1, discretization=args.disc, device=local_rank)
+    plan = capi.Plan(D, M, batch=B, discretization=args.disc, device=local_rank)
     plan.set_timing(True)
     dq = torch.from_numpy(q_host).cuda()
-    outs = [torch.zeros(3 * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
+    outs = [torch.zeros(B * 3 * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
     gather_bufs = None
     if world > 1 and rank == 0 and not args.no_gather:
-        gather_bufs = [[torch.zeros(3 * M, 2, dtype=torch.float64, device="cuda") for _ in range(world)]
+        gather_bufs = [[torch.zeros(B * 3 * M, 2, dtype=torch.float64,
+                                    device="cpu" if args.rehearse_gloo else "cuda") for _ in range(world)]
                        for _ in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -85,8 +109,11 @@ def main():
             # the buffer written two steps ago must have been gathered before it is reused
             if len(pending) >= 2:
                 pending.pop(0).wait()
-            w = dist.gather(torch.view_as_real(buf), gather_bufs[i % 2] if rank == 0 else None, dst=0,
-                            async_op=True)
+            src = torch.view_as_real(buf)
+            if args.rehearse_gloo:
+                torch.cuda.synchronize()
+                src = src.cpu()
+            w = dist.gather(src, gather_bufs[i % 2] if rank == 0 else None, dst=0, async_op=True)
             pending.append(w)
 
     def barrier():
@@ -126,12 +153,12 @@ def main():
     if rc != 0:
         raise RuntimeError("device status rc=%d: %s" % (rc, capi.last_error()))
 
-    t_all = torch.tensor([wall_ms], dtype=torch.float64, device="cuda")
+    t_all = torch.tensor([wall_ms], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     wall_ms_max = float(t_all.item())
     ms_per_step = wall_ms_max / args.steps
-    value = world * D / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
+    value = world * B * D / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
 
     # ---- tree-only timing with HIP events over many passes (roofline) -----------------------
     roof = None
@@ -144,11 +171,11 @@ def main():
             torch.cuda.synchronize()
             tms.append(plan.last_ms(0))
         t_tree = float(np.median(tms))
-        bt = bytes_tree(D, deg0)
+        bt = B * bytes_tree(D, deg0)
         achieved = bt / (t_tree * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_tree_traffic.json")
-        if os.path.exists(tpath) and args.log2D == 20 and args.disc == "2SPLIT2_MODAL":
+        if os.path.exists(tpath) and args.log2D == 20 and args.disc == "2SPLIT2_MODAL" and not cfg3:
             # measured HBM bytes of the same launches (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
             # separate passes, FETCH doubled as the microarch guide prescribes); see profiles/
             with open(tpath) as f:
@@ -162,28 +189,33 @@ def main():
             from oracle import load_oracle
             orc = load_oracle()
             Dc = min(D, 1 << 20)
-            qc = S.sech_focusing(Dc)
-            tc0 = time.perf_counter()
-            rcc, ref = orc.fnft_nsev(qc, T, Dc, XI, kappa=1, disc=args.disc, cstype="BOTH")
-            tc = time.perf_counter() - tc0
-            res = outs[(args.steps - 1) % 2].cpu().numpy() if Dc == D else None
-            err = None
-            if res is not None and rcc == 0:
-                err = {k: float(S.rel_err(res[j * M:(j + 1) * M], ref[j * M:(j + 1) * M]))
-                       for j, k in enumerate(("rho", "a", "b"))}
-            cpu = {"value": round(Dc / tc / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                   "sample": "1 signal, D=M=2^%d, %s, oracle/fnft_oracle.c single thread, %.1f s"
-                             % (int(math.log2(Dc)), args.disc, tc),
+            nc = 8 if cfg3 else 1   # bounded sample: the first nc signals of this rank
+            qc = q_host[:nc] if cfg3 else S.sech_focusing(Dc)[None, :]
+            res = outs[(args.steps - 1) % 2].cpu().numpy().reshape(B, 3, M) if Dc == D else None
+            tc = 0.0
+            worst = [0.0, 0.0, 0.0]
+            for k in range(nc):
+                tc0 = time.perf_counter()
+                rcc, ref = orc.fnft_nsev(qc[k], T, Dc, XI, kappa=1, disc=args.disc, cstype="BOTH")
+                tc += time.perf_counter() - tc0
+                if res is not None and rcc == 0:
+                    for j in range(3):
+                        worst[j] = max(worst[j], float(S.rel_err(res[k, j], ref[j * M:(j + 1) * M])))
+            err = dict(zip(("rho", "a", "b"), worst)) if res is not None else None
+            cpu = {"value": round(nc * Dc / tc / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                   "sample": "%d signal(s), D=M=2^%d, %s, oracle/fnft_oracle.c single thread, %.1f s"
+                             % (nc, int(math.log2(Dc)), args.disc, tc),
                    "host_cpus": os.cpu_count(), "gpu_vs_cpu_rel_l1": err}
 
     if rank == 0:
         line = {
-            "metric": "Msamples/s fnft_nsev contspec (D=2^%d fp64)" % args.log2D,
+            "metric": "Msamples/s fnft_nsev contspec (D=2^%d fp64)%s" % (args.log2D, " batch" if cfg3 else ""),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "fnft_nsev D=M=2^%d contspec (a,b + reflection), %s, 1 signal per GPU"
-                                   % (args.log2D, args.disc),
+            "config": {"workload": "fnft_nsev D=M=2^%d contspec (a,b + reflection), %s, %d signal%s per GPU%s"
+                                   % (args.log2D, args.disc, B, "" if B == 1 else "s",
+                                      " (configs[2]: 512 signals over 8 GPUs)" if cfg3 else ""),
                        "per_step_gather": bool(world > 1 and not args.no_gather),
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
             "roofline": roof, "cpu_baseline": cpu,
