@@ -178,10 +178,18 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
     case fnft_nse_discretization_2SPLIT3S:
     case fnft_nse_discretization_2SPLIT4A:
     case fnft_nse_discretization_2SPLIT4B:
+    case fnft_nse_discretization_2SPLIT5A:
+    case fnft_nse_discretization_2SPLIT5B:
+    case fnft_nse_discretization_2SPLIT6A:
+    case fnft_nse_discretization_2SPLIT6B:
+    case fnft_nse_discretization_2SPLIT7A:
+    case fnft_nse_discretization_2SPLIT7B:
+    case fnft_nse_discretization_2SPLIT8A:
+    case fnft_nse_discretization_2SPLIT8B:
         break;
     default:
         return E_NOT_YET_IMPLEMENTED(discretization,
-                                     "GPU path covers the 2SPLIT schemes of degree <= 4.");
+                                     "GPU path covers the 2SPLIT schemes (orders 1 to 8).");
     }
     if (kappa == +1 && bound_states != NULL)
         return E_NOT_YET_IMPLEMENTED(bound_states, "Pass bound_states = NULL for the continuous spectrum.");

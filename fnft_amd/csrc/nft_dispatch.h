@@ -18,6 +18,12 @@ template <int DEG> struct KCoeffs {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_coeffs<DEG>(p); }
 };
+struct KCoeffsProg {
+    using Params = CoeffProgParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_coeffs_prog(p); }
+};
 template <int DEG> struct LeafCfg {
     static constexpr int SPT = (DEG == 1) ? 8 : (DEG == 2 ? 4 : 2);
 };

@@ -314,6 +314,70 @@ template <int DEG> FA_DEV void body_coeffs(const CoeffParams &P)
     P.wexp[gid] = 0;
 }
 
+// Splitting schemes of order 5..8 (fnft__akns_fscatter.c:435-912): the coefficients are sums of
+// monomials in the elements of e^{bB} for a few step fractions b; the list ("program") is built
+// on the host by nft_schemes.h and is the same for every sample.
+struct CoeffProgParams {
+    CoeffParams c;
+    const double *bfrac;          // nB fractions of eps_t
+    const int *tgt_ptr;           // 4*(deg+1)+1
+    const double *mw;             // monomial weights
+    const unsigned char *mfac;    // maxf ids per monomial, 255 = unused
+    int nB, maxf;
+};
+
+FA_DEV void body_coeffs_prog(const CoeffProgParams &Q)
+{
+    const CoeffParams &P = Q.c;
+    const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long n = (long long)P.batch * P.Dpad;
+    if (gid >= n) return;
+    const int b = (int)(gid / P.Dpad), j = (int)(gid % P.Dpad);
+    const int deg = P.deg;
+    const bool pad = j >= P.D;
+    cplx el[24];
+    if (!pad) {
+        const size_t src = (size_t)b * P.D + (size_t)(P.D - 1 - j);
+        const cplx q = P.q[src];
+        const cplx r = P.r ? P.r[src] : (P.kappa == 1 ? cmake(-q.x, q.y) : cmake(q.x, -q.y));
+        for (int i = 0; i < Q.nB; i++) {
+            const StepExp e = zero_freq_step(P.eps_t * Q.bfrac[i], q, r);
+            el[3 * i] = e.c;
+            el[3 * i + 1] = e.qs;
+            el[3 * i + 2] = e.rs;
+        }
+    }
+    for (int e = 0; e < 4; e++) {
+        if (P.ne == 2 && (e & 1)) continue;
+        const int s = (P.ne == 2) ? (e >> 1) : e;
+        cplx *body = P.body + (size_t)s * P.plane + (size_t)gid * deg;
+        for (int k = 0; k <= deg; k++) {
+            cplx acc = cmake(0.0, 0.0);
+            if (pad) {
+                // z^deg * I in the general form, diag(1, z^deg) in the symmetric form (body_coeffs)
+                const bool one = (P.ne == 4) ? ((e == 0 || e == 3) && k == 0)
+                                             : ((e == 0 && k == deg) || (e == 3 && k == 0));
+                if (one) acc = cmake(1.0, 0.0);
+            } else {
+                const int t = e * (deg + 1) + k;
+                for (int m = Q.tgt_ptr[t]; m < Q.tgt_ptr[t + 1]; m++) {
+                    cplx prod = cmake(Q.mw[m], 0.0);
+                    for (int f = 0; f < Q.maxf; f++) {
+                        const int id = Q.mfac[(size_t)m * Q.maxf + f];
+                        if (id == 255) break;
+                        prod = prod * el[id];
+                    }
+                    acc = acc + prod;
+                }
+            }
+            if (k < deg) body[k] = acc;
+            else P.tail[(size_t)s * n + gid] = acc;
+        }
+    }
+    P.scale[gid] = 1.0;
+    P.wexp[gid] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1+: leaf kernel = coefficients of SPT consecutive samples AND their ordered product, all in
 // registers of one lane (levels 0 .. log2(SPT)-1 of the tree never touch HBM).  Replaces the

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "nft_dispatch.h"
+#include "nft_schemes.h"
 
 // return codes (include/fnft_errwarn.h:44-94)
 enum {
@@ -47,10 +48,15 @@ inline int nft_akns_degree(int akns_disc)
     case 8: case 10: return 2;                                   // 3S, 4B
     case 6: case 7: return 3;                                    // 3A, 3B
     case 9: return 4;                                            // 4A
+    case 14: return 6;                                           // 6B
+    case 13: case 18: return 12;                                 // 6A, 8B
+    case 11: case 12: return 15;                                 // 5A, 5B
+    case 17: return 24;                                          // 8A
+    case 15: case 16: return 105;                                // 7A, 7B
     default: return 0;
     }
 }
-// fnft__nse_discretization.c:108-200 (upsampling-factor-1 schemes of degree <= 4); -1 otherwise
+// fnft__nse_discretization.c:108-200 (upsampling-factor-1 splitting schemes); -1 otherwise
 inline int nft_nse_to_akns(int nse_disc)
 {
     switch (nse_disc) {
@@ -65,6 +71,8 @@ inline int nft_nse_to_akns(int nse_disc)
     case 9: return 8;    // 2SPLIT3S
     case 10: return 9;   // 2SPLIT4A
     case 11: return 10;  // 2SPLIT4B
+    case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19:
+        return nse_disc - 1;   // 2SPLIT5A .. 2SPLIT8B -> akns 11 .. 18
     default: return -1;
     }
 }
@@ -109,6 +117,11 @@ public:
     unsigned long long *max2[2] = {nullptr, nullptr};  // ping-pong across split levels
     int *wexp[2] = {nullptr, nullptr};  // per matrix, ping-pong with body/tail/scale
     int *status = nullptr;
+    // monomial program of the order 5..8 schemes (nft_schemes.h), device copies
+    double *prog_bfrac = nullptr, *prog_mw = nullptr;
+    int *prog_ptr = nullptr;
+    unsigned char *prog_fac = nullptr;
+    int prog_nB = 0, prog_maxf = 0;
     cplx *Y = nullptr, *Z = nullptr, *Z2 = nullptr;   // Z ping-pongs when spectral doubling is on
     cplx *chY = nullptr, *chV = nullptr, *chH = nullptr;
     cplx *tm_out = nullptr;
@@ -194,7 +207,22 @@ public:
         }
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
         ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
+        CoeffProgramHost prog;
+        const bool has_prog = akns_disc >= 11 && akns_disc <= 18;   // 2SPLIT5A .. 2SPLIT8B
+        if (has_prog) {
+            if (!nft_build_coeff_program(akns_disc, deg0, prog)) return NFT_EC_NOT_YET_IMPLEMENTED;
+            ok = ok && alloc(prog_bfrac, prog.bfrac.size()) && alloc(prog_mw, prog.mw.size())
+                 && alloc(prog_ptr, prog.tgt_ptr.size()) && alloc(prog_fac, prog.mfac.size());
+        }
         if (!ok) return NFT_EC_NOMEM;
+        if (has_prog) {
+            be.h2d(prog_bfrac, prog.bfrac.data(), prog.bfrac.size() * sizeof(double));
+            be.h2d(prog_mw, prog.mw.data(), prog.mw.size() * sizeof(double));
+            be.h2d(prog_ptr, prog.tgt_ptr.data(), prog.tgt_ptr.size() * sizeof(int));
+            be.h2d(prog_fac, prog.mfac.data(), prog.mfac.size());
+            prog_nB = (int)prog.bfrac.size();
+            prog_maxf = prog.maxf;
+        }
         upload_twiddles();
         return NFT_SUCCESS;
     }
@@ -204,6 +232,7 @@ public:
         for (int i = 0; i < 2; i++) { be.free(body[i]); be.free(tail[i]); be.free(scale[i]); be.free(wexp[i]); }
         be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
         be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
+        be.free(prog_bfrac); be.free(prog_mw); be.free(prog_ptr); be.free(prog_fac);
     }
 
     void upload_twiddles()
@@ -262,7 +291,17 @@ public:
             start_d = (size_t)deg0 * (size_t)spt;
             return NFT_SUCCESS;
         }
-        if (!dispatch_coeffs(be, p)) return NFT_EC_NOT_YET_IMPLEMENTED;
+        if (prog_ptr != nullptr) {
+            // schemes of order 5..8: generated coefficient program; the symmetric form can start at
+            // level 0 because every level is an FFT level (deg0 > kSchoolMaxDeg)
+            ne = (use_sym && d_r == nullptr) ? 2 : 4;
+            CoeffProgParams pp;
+            pp.c = p;
+            pp.c.ne = ne;
+            pp.bfrac = prog_bfrac; pp.tgt_ptr = prog_ptr; pp.mw = prog_mw; pp.mfac = prog_fac;
+            pp.nB = prog_nB; pp.maxf = prog_maxf;
+            be.template run<KCoeffsProg>((int)((n0 + 63) / 64), 1, pp);
+        } else if (!dispatch_coeffs(be, p)) return NFT_EC_NOT_YET_IMPLEMENTED;
         start_n = n0;
         start_d = (size_t)deg0;
         return NFT_SUCCESS;

@@ -407,6 +407,11 @@ size_t orc_akns_degree(int disc)
     case ORC_AKNS_2SPLIT3S: case ORC_AKNS_2SPLIT4B: return 2;
     case ORC_AKNS_2SPLIT3A: case ORC_AKNS_2SPLIT3B: return 3;
     case ORC_AKNS_2SPLIT4A: return 4;
+    case ORC_AKNS_2SPLIT6B: return 6;
+    case ORC_AKNS_2SPLIT6A: case ORC_AKNS_2SPLIT8B: return 12;
+    case ORC_AKNS_2SPLIT5A: case ORC_AKNS_2SPLIT5B: return 15;
+    case ORC_AKNS_2SPLIT8A: return 24;
+    case ORC_AKNS_2SPLIT7A: case ORC_AKNS_2SPLIT7B: return 105;
     default: return 0;
     }
 }
@@ -426,6 +431,14 @@ int orc_nse_to_akns(int d)
     case ORC_NSE_2SPLIT3S: return ORC_AKNS_2SPLIT3S;
     case ORC_NSE_2SPLIT4A: return ORC_AKNS_2SPLIT4A;
     case ORC_NSE_2SPLIT4B: return ORC_AKNS_2SPLIT4B;
+    case ORC_NSE_2SPLIT5A: return ORC_AKNS_2SPLIT5A;
+    case ORC_NSE_2SPLIT5B: return ORC_AKNS_2SPLIT5B;
+    case ORC_NSE_2SPLIT6A: return ORC_AKNS_2SPLIT6A;
+    case ORC_NSE_2SPLIT6B: return ORC_AKNS_2SPLIT6B;
+    case ORC_NSE_2SPLIT7A: return ORC_AKNS_2SPLIT7A;
+    case ORC_NSE_2SPLIT7B: return ORC_AKNS_2SPLIT7B;
+    case ORC_NSE_2SPLIT8A: return ORC_AKNS_2SPLIT8A;
+    case ORC_NSE_2SPLIT8B: return ORC_AKNS_2SPLIT8B;
     default: return -1;
     }
 }
@@ -441,6 +454,101 @@ static step_exp zero_freq_step(double h, orc_cplx q, orc_cplx r)
     e.qs = q * del;
     e.rs = r * del;
     return e;
+}
+
+/* ---- splitting schemes of order 5..8 (fnft__akns_fscatter.c:435-912) ------------------------
+ * The reference spells these out coefficient by coefficient.  They are the Richardson-type
+ * combinations  sum_n w_n Psi_n(h)  of the paper behind the library (Prins & Wahls, "Higher order
+ * exponential splittings for the fast non-linear Fourier transform of the KdV equation", 2018):
+ *   odd order p, n = 1,3,..,p:  Psi_n = n alternating Lie-Trotter sub-steps,
+ *        "A": e^{A/n} e^{2B/n} e^{2A/n} ... e^{2A/n} e^{B/n},   "B": roles of A and B swapped;
+ *   even order p, n = 1,..,p/2: Psi_n = n Strang sub-steps,
+ *        "A": e^{A/2n} e^{B/n} e^{A/n} ... e^{B/n} e^{A/2n},    "B": swapped;
+ *   w_n = n^(p-1) / prod_{m != n} (n^2 - m^2)   (625/384, -81/128, 1/192 for p = 5, :456-459).
+ * With z = e^{2 i lambda h/deg}, e^{aA} is diag(1, z^{a*deg}) up to a scalar (compare 2SPLIT1A/1B,
+ * :150-203) and e^{bB} = expm([[0,q],[r,0]] b h) (:46-59).  Here the products are multiplied out as
+ * dense 2x2 polynomial matrices; the golden vectors of test/fnft__akns_fscatter/ pin the result. */
+typedef struct { int is_B; int num, den; } split_factor;  /* fraction num/den of the step */
+
+static size_t split_sequence(int order_odd, int b_first, int n, split_factor *f)
+{
+    size_t k = 0;
+    if (order_odd) { /* X(1/n) Y(2/n) X(2/n) ... X(2/n) Y(1/n), (n+1)/2 of each */
+        const int cnt = (n + 1) / 2;
+        for (int i = 0; i < cnt; i++) {
+            f[k++] = (split_factor){b_first, (i == 0) ? 1 : 2, n};
+            f[k++] = (split_factor){!b_first, (i == cnt - 1) ? 1 : 2, n};
+        }
+    } else {         /* X(1/2n) [Y(1/n) X(1/n)]^(n-1) Y(1/n) X(1/2n) */
+        f[k++] = (split_factor){b_first, 1, 2 * n};
+        for (int i = 0; i < n; i++) {
+            f[k++] = (split_factor){!b_first, 1, n};
+            f[k++] = (split_factor){b_first, 1, (i == n - 1) ? 2 * n : n};
+        }
+    }
+    return k;
+}
+
+static int split_scheme(int disc, int *order, int *b_first)
+{
+    switch (disc) {
+    case ORC_AKNS_2SPLIT5A: *order = 5; *b_first = 0; return 1;
+    case ORC_AKNS_2SPLIT5B: *order = 5; *b_first = 1; return 1;
+    case ORC_AKNS_2SPLIT6A: *order = 6; *b_first = 0; return 1;
+    case ORC_AKNS_2SPLIT6B: *order = 6; *b_first = 1; return 1;
+    case ORC_AKNS_2SPLIT7A: *order = 7; *b_first = 0; return 1;
+    case ORC_AKNS_2SPLIT7B: *order = 7; *b_first = 1; return 1;
+    case ORC_AKNS_2SPLIT8A: *order = 8; *b_first = 0; return 1;
+    case ORC_AKNS_2SPLIT8B: *order = 8; *b_first = 1; return 1;
+    default: return 0;
+    }
+}
+
+/* coefficients of one sample, out[e*(deg+1) + k], highest power first */
+static void split_sample(int order, int b_first, size_t deg, double eps_t, orc_cplx q, orc_cplx r,
+                         orc_cplx *out, orc_cplx *work)
+{
+    const size_t w = deg + 1;
+    const int odd = order & 1;
+    const int nterms = odd ? (order + 1) / 2 : order / 2;
+    orc_cplx *P[4] = {work, work + w, work + 2 * w, work + 3 * w}; /* ascending powers */
+    for (size_t i = 0; i < 4 * w; i++) out[i] = 0.0;
+    for (int t = 0; t < nterms; t++) {
+        const int n = odd ? 2 * t + 1 : t + 1;
+        long double wn = powl((long double)n, (long double)(order - 1 - (odd ? 0 : 1)));
+        /* odd p: n^(p-1); even p: n^(p-2) -- both are n^(2*(nterms-1)) */
+        wn = powl((long double)n, 2.0L * (nterms - 1));
+        for (int u = 0; u < nterms; u++) {
+            const int m = odd ? 2 * u + 1 : u + 1;
+            if (m != n) wn /= (long double)(n * n - m * m);
+        }
+        split_factor f[64];
+        const size_t nf = split_sequence(odd, b_first, n, f);
+        for (size_t i = 0; i < 4 * w; i++) work[i] = 0.0;
+        P[0][0] = 1.0;
+        P[3][0] = 1.0;
+        for (size_t i = 0; i < nf; i++) {
+            if (!f[i].is_B) { /* right-multiply by diag(1, z^k): shift the second column */
+                const size_t k = (size_t)f[i].num * deg / (size_t)f[i].den;
+                for (int row = 0; row < 2; row++) {
+                    orc_cplx *c = P[2 * row + 1];
+                    for (size_t j = w; j-- > 0;) c[j] = (j >= k) ? c[j - k] : 0.0;
+                }
+            } else {
+                const step_exp e = zero_freq_step(eps_t * (double)f[i].num / (double)f[i].den, q, r);
+                for (int row = 0; row < 2; row++) {
+                    orc_cplx *c0 = P[2 * row], *c1 = P[2 * row + 1];
+                    for (size_t j = 0; j < w; j++) {
+                        const orc_cplx a = c0[j], b = c1[j];
+                        c0[j] = a * e.c + b * e.rs;
+                        c1[j] = a * e.qs + b * e.c;
+                    }
+                }
+            }
+        }
+        for (int e = 0; e < 4; e++)
+            for (size_t j = 0; j < w; j++) out[(size_t)e * w + (deg - j)] += (double)wn * P[e][j];
+    }
 }
 
 size_t orc_akns_fscatter_numel(size_t D, int disc)
@@ -538,7 +646,18 @@ int orc_akns_coeffs(size_t D, const orc_cplx *q, const orc_cplx *r, double eps_t
             p22[0] = p11[2]; p22[1] = p11[1]; p22[2] = p11[0];
             break;
         }
-        default: return ORC_EC_INVALID_ARGUMENT;
+        default: {
+            int order, b_first;
+            if (!split_scheme(disc, &order, &b_first)) return ORC_EC_INVALID_ARGUMENT;
+            orc_cplx *tmp = malloc(8 * w * sizeof(orc_cplx));
+            if (!tmp) return ORC_EC_NOMEM;
+            split_sample(order, b_first, deg, eps_t, qi, ri, tmp, tmp + 4 * w);
+            for (size_t k = 0; k < w; k++) {
+                p11[k] = tmp[k]; p12[k] = tmp[w + k]; p21[k] = tmp[2 * w + k]; p22[k] = tmp[3 * w + k];
+            }
+            free(tmp);
+            break;
+        }
         }
     }
     return ORC_SUCCESS;

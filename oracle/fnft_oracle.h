@@ -45,7 +45,8 @@ enum orc_nse_disc {
 enum orc_akns_disc {
     ORC_AKNS_2SPLIT2_MODAL = 0, ORC_AKNS_2SPLIT1A, ORC_AKNS_2SPLIT1B, ORC_AKNS_2SPLIT2A,
     ORC_AKNS_2SPLIT2B, ORC_AKNS_2SPLIT2S, ORC_AKNS_2SPLIT3A, ORC_AKNS_2SPLIT3B, ORC_AKNS_2SPLIT3S,
-    ORC_AKNS_2SPLIT4A, ORC_AKNS_2SPLIT4B
+    ORC_AKNS_2SPLIT4A, ORC_AKNS_2SPLIT4B, ORC_AKNS_2SPLIT5A, ORC_AKNS_2SPLIT5B, ORC_AKNS_2SPLIT6A,
+    ORC_AKNS_2SPLIT6B, ORC_AKNS_2SPLIT7A, ORC_AKNS_2SPLIT7B, ORC_AKNS_2SPLIT8A, ORC_AKNS_2SPLIT8B
 };
 
 /* contspec_type values of fnft_nsev_cstype_t (include/fnft_nsev.h:130-134). */

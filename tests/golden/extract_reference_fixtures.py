@@ -100,8 +100,9 @@ def main():
         name = re.search(r"akns_discretization_(\w+)\s*;", src).group(1)
         eps = float(re.search(r"eps_t\s*=\s*([0-9.eE+-]+)\s*;", src).group(1))
         D = int(re.search(r"\bD\s*=\s*(\d+)", src).group(1))
+        tol_eps = float(re.search(r"err_bnd\s*=\s*([0-9.]+)\s*\*\s*EPSILON", src).group(1))
         schemes[name] = {
-            "D": D, "eps_t": eps,
+            "D": D, "eps_t": eps, "tol_rel_l1": tol_eps * 2.220446049250313e-16,
             "result_exact": [c2l(z) for z in array_init(src, "result_exact")],
         }
     out["akns_fscatter"] = {

@@ -127,3 +127,16 @@ def tree_direct(p, deg, n):
             nxt.append(mats[-1])
         mats = nxt
     return mats[0]
+
+
+def contspec_tol(oracle, q, T, kappa, disc, floor):
+    """Tolerance for comparing two FFT-tree evaluations of the same spectrum.  Both carry an
+    absolute error of a few eps * max|c| per coefficient c of the transfer matrix (times 2^W);
+    evaluating a polynomial of degree deg adds these up to ~sqrt(deg) * eps * max|c|.  For the
+    low-order schemes on fine grids max|c| ~ 1 and the floor applies; the order 5..8 schemes on
+    coarse grids have max|c| up to 1e4 (Richardson weights, large steps) and the oracle itself is
+    that far from a direct long-double evaluation."""
+    eps_t = (T[1] - T[0]) / (len(q) - 1)
+    rc, deg, tm, W = oracle.nse_fscatter(q, eps_t, kappa, disc)
+    cmax = float(np.max(np.abs(tm))) * 2.0 ** W
+    return max(floor, 100 * 2.220446049250313e-16 * cmax * np.sqrt(deg))

@@ -92,7 +92,7 @@ def test_unknown_and_unsupported_options(capi):
     o.bound_state_localization = 1
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     o = capi.default_opts()
-    o.discretization = capi.NSE_DISC["2SPLIT8B"]
+    o.discretization = capi.NSE_DISC["4SPLIT4A"]
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     o = capi.default_opts()
     o.richardson_extrapolation_flag = 1                                           # accepted; needs the GPU
