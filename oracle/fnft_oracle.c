@@ -153,6 +153,67 @@ int orc_fft(size_t len, const orc_cplx *in, orc_cplx *out, int sign)
     return rc;
 }
 
+/* DFT of any length: the reference hands any D to KissFFT, which falls back to generic radix-p
+ * butterflies (kiss_fft.c:220-279); here lengths with other prime factors go through Bluestein
+ * with the chirp exp(sign*i*pi*n^2/len) formed from n^2 mod 2len in extended precision. */
+int orc_dft(size_t len, const orc_cplx *in, orc_cplx *out, int sign)
+{
+    orc_plan pl;
+    int rc = plan_init(&pl, len, sign);
+    if (rc == ORC_SUCCESS) {
+        plan_exec(&pl, in, out);
+        plan_free(&pl);
+        return rc;
+    }
+    plan_free(&pl);
+    const size_t L = orc_next_fast_size(2 * len - 1);
+    orc_cplx *c = malloc(len * sizeof(orc_cplx)), *a = calloc(L, sizeof(orc_cplx)),
+             *b = calloc(L, sizeof(orc_cplx)), *fa = malloc(L * sizeof(orc_cplx)),
+             *fb = malloc(L * sizeof(orc_cplx));
+    if (!c || !a || !b || !fa || !fb) { free(c); free(a); free(b); free(fa); free(fb); return ORC_EC_NOMEM; }
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (size_t n = 0; n < len; n++) {
+        const unsigned long long r = ((unsigned long long)n * n) % (2ull * len);
+        const long double ang = (long double)sign * pi * (long double)r / (long double)len;
+        c[n] = (double)cosl(ang) + I * (double)sinl(ang);   /* w^{n^2/2} */
+    }
+    for (size_t n = 0; n < len; n++) {
+        a[n] = in[n] * c[n];
+        b[n] = conj(c[n]);
+        if (n) b[L - n] = conj(c[n]);
+    }
+    rc = orc_fft(L, a, fa, -1);
+    if (rc == ORC_SUCCESS) rc = orc_fft(L, b, fb, -1);
+    if (rc == ORC_SUCCESS) {
+        for (size_t k = 0; k < L; k++) fa[k] *= fb[k];
+        rc = orc_fft(L, fa, a, +1);
+    }
+    if (rc == ORC_SUCCESS)
+        for (size_t k = 0; k < len; k++) out[k] = c[k] * a[k] / (double)L;
+    free(c); free(a); free(b); free(fa); free(fb);
+    return rc;
+}
+
+/* fnft__misc.c:326-407: band-limited shift of a periodically continued signal by delta */
+int orc_misc_resample(size_t D, double eps_t, const orc_cplx *q, double delta, orc_cplx *q_new)
+{
+    if (!q || D <= 2 || !q_new || eps_t == 0.0) return ORC_EC_INVALID_ARGUMENT;
+    orc_cplx *X = malloc(D * sizeof(orc_cplx));
+    if (!X) return ORC_EC_NOMEM;
+    int rc = orc_dft(D, q, X, -1);
+    if (rc == ORC_SUCCESS) {
+        const double scl = (double)D * eps_t, pi = acos(-1.0);
+        for (size_t i = 0; i < D; i++) {
+            const double freq = (i < D / 2) ? (double)i / scl : ((double)i - (double)D) / scl;
+            X[i] *= cexp(2 * I * pi * delta * freq);
+        }
+        rc = orc_dft(D, X, q_new, +1);
+        for (size_t i = 0; i < D; i++) q_new[i] /= (double)D;
+    }
+    free(X);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* small helpers                                                                                */
 /* ------------------------------------------------------------------------------------------ */
@@ -404,9 +465,9 @@ size_t orc_akns_degree(int disc)
     switch (disc) {
     case ORC_AKNS_2SPLIT2_MODAL: case ORC_AKNS_2SPLIT1A: case ORC_AKNS_2SPLIT1B:
     case ORC_AKNS_2SPLIT2A: case ORC_AKNS_2SPLIT2B: case ORC_AKNS_2SPLIT2S: return 1;
-    case ORC_AKNS_2SPLIT3S: case ORC_AKNS_2SPLIT4B: return 2;
+    case ORC_AKNS_2SPLIT3S: case ORC_AKNS_2SPLIT4B: case ORC_AKNS_4SPLIT4B: return 2;
     case ORC_AKNS_2SPLIT3A: case ORC_AKNS_2SPLIT3B: return 3;
-    case ORC_AKNS_2SPLIT4A: return 4;
+    case ORC_AKNS_2SPLIT4A: case ORC_AKNS_4SPLIT4A: return 4;
     case ORC_AKNS_2SPLIT6B: return 6;
     case ORC_AKNS_2SPLIT6A: case ORC_AKNS_2SPLIT8B: return 12;
     case ORC_AKNS_2SPLIT5A: case ORC_AKNS_2SPLIT5B: return 15;
@@ -439,6 +500,8 @@ int orc_nse_to_akns(int d)
     case ORC_NSE_2SPLIT7B: return ORC_AKNS_2SPLIT7B;
     case ORC_NSE_2SPLIT8A: return ORC_AKNS_2SPLIT8A;
     case ORC_NSE_2SPLIT8B: return ORC_AKNS_2SPLIT8B;
+    case ORC_NSE_4SPLIT4A: return ORC_AKNS_4SPLIT4A;
+    case ORC_NSE_4SPLIT4B: return ORC_AKNS_4SPLIT4B;
     default: return -1;
     }
 }
@@ -626,7 +689,7 @@ int orc_akns_coeffs(size_t D, const orc_cplx *q, const orc_cplx *r, double eps_t
             p22[0] = p11[2]; p22[2] = p11[0];
             break;
         }
-        case ORC_AKNS_2SPLIT4A: { /* :362-401 */
+        case ORC_AKNS_2SPLIT4A: case ORC_AKNS_4SPLIT4A: { /* :362-401 */
             step_exp e2 = zero_freq_step(2 * h, qi, ri), e4 = zero_freq_step(4 * h, qi, ri);
             p11[2] = 4 * e2.qs * e2.rs / 3; p11[4] = (4 * e2.c * e2.c - e4.c) / 3;
             p12[1] = p12[3] = 4 * e2.c * e2.qs / 3; p12[2] = -e4.qs / 3;
@@ -634,7 +697,7 @@ int orc_akns_coeffs(size_t D, const orc_cplx *q, const orc_cplx *r, double eps_t
             p22[0] = p11[4]; p22[2] = p11[2];
             break;
         }
-        case ORC_AKNS_2SPLIT4B: { /* :402-433 */
+        case ORC_AKNS_2SPLIT4B: case ORC_AKNS_4SPLIT4B: { /* :402-433 */
             step_exp eh = zero_freq_step(0.5 * h, qi, ri), e1 = zero_freq_step(h, qi, ri);
             p11[0] = (4 * e1.c * eh.qs * eh.rs - e1.qs * e1.rs) / 3;
             p11[1] = 4 * (e1.qs * eh.c * eh.rs + e1.rs * eh.c * eh.qs) / 3;
@@ -720,12 +783,22 @@ static void phase_factors(int nse_disc, double eps_t, size_t D, const double *T,
 }
 
 /* fnft_nsev.c:744-891, fast (polynomial) branch */
+size_t orc_nse_upsampling(int nse_disc)
+{
+    return (nse_disc == ORC_NSE_4SPLIT4A || nse_disc == ORC_NSE_4SPLIT4B) ? 2 : 1;
+}
+
 int orc_nsev_contspec(size_t deg, int32_t W, const orc_cplx *tm, const double *T, size_t D,
                       const double *XI, size_t M, orc_cplx *result, int nse_disc, int cstype)
 {
     const int a_disc = orc_nse_to_akns(nse_disc);
     if (a_disc < 0) return ORC_EC_INVALID_ARGUMENT;
-    const double deg1 = (double)orc_akns_degree(a_disc);
+    /* D counts the preprocessed samples; step size and phase factors refer to D_given = D/upsampling
+     * (fnft_nsev.c:766-774), lambda -> z uses degree*upsampling (fnft__akns_discretization.c:204-219) */
+    const size_t ups = orc_nse_upsampling(nse_disc);
+    const size_t D_eff = D;
+    D = D_eff / ups;
+    const double deg1 = (double)(orc_akns_degree(a_disc) * ups);
     const double eps_t = (T[1] - T[0]) / (double)(D - 1);
     const double eps_xi = (XI[1] - XI[0]) / (double)(M - 1);
     orc_cplx *H = malloc(2 * M * sizeof(orc_cplx));
@@ -768,31 +841,85 @@ int orc_nsev_contspec(size_t deg, int32_t W, const orc_cplx *tm, const double *T
 static int orc_nsev_base(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
                          const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag);
 
-/* fnft_nsev.c:133-453, contspec-only subset, with Richardson extrapolation (:316-406): a second
- * transform of every other sample (fnft__nse_discretization.c:426-473 subsampling rule) and
- * (s*fine - coarse)/(s - 1), s = (eps_sub/eps)^order, order 2 for every 2SPLIT scheme
- * (fnft__akns_discretization.c:157-192), on the grid points with |xi| < 0.9*pi/(2*eps_sub). */
-int orc_fnft_nsev_ex(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
-                     const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag,
-                     int richardson_flag)
+/* fnft__nse_discretization.c:386-656 restricted to the splitting schemes: subsampling
+ * (:419-427, :466-473) and, for 4SPLIT4A/B, the two band-limited resamplings at -/+ sqrt(3)/6 of
+ * the (subsampled) step combined with the weights of fnft__akns_discretization.c:284-298
+ * (:474-503).  *q_pre gets Dsub*upsampling entries; first_last as at :650-651. */
+int orc_nse_preprocess(size_t D, const orc_cplx *q, double eps_t, size_t *Dsub_ptr, orc_cplx **q_pre,
+                       size_t *first_last, int nse_disc)
 {
-    int rc = orc_nsev_base(D, q, T, M, contspec, XI, kappa, nse_disc, cstype, normalization_flag);
-    if (rc != ORC_SUCCESS || !richardson_flag || !contspec || M == 0) return rc;
-    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
-    size_t Dsub = D / 2; /* CEIL(D/2) on integers, fnft_nsev.c:376 */
+    if (D < 2 || !q || !Dsub_ptr || !q_pre || !(eps_t > 0.0) || !first_last) return ORC_EC_INVALID_ARGUMENT;
+    if (orc_nse_to_akns(nse_disc) < 0) return ORC_EC_INVALID_ARGUMENT;
+    size_t Dsub = *Dsub_ptr;
     if (Dsub < 2) Dsub = 2;
     if (Dsub > D) Dsub = D;
     const size_t nskip = (size_t)round((double)D / (double)Dsub);
     Dsub = (size_t)round((double)D / (double)nskip);
+    const size_t ups = orc_nse_upsampling(nse_disc);
+    const size_t D_eff = Dsub * ups;
+    orc_cplx *out = malloc(D_eff * sizeof(orc_cplx));
+    if (!out) return ORC_EC_NOMEM;
+    int rc = ORC_SUCCESS;
+    if (ups == 1) {
+        for (size_t i = 0; i < D_eff; i++) out[i] = q[i * nskip];
+    } else {
+        orc_cplx *q1 = malloc(D * sizeof(orc_cplx)), *q2 = malloc(D * sizeof(orc_cplx));
+        if (!q1 || !q2) rc = ORC_EC_NOMEM;
+        const double scl = sqrt(3.0) / 6.0;
+        if (rc == ORC_SUCCESS) rc = orc_misc_resample(D, eps_t, q, -eps_t * scl * (double)nskip, q1);
+        if (rc == ORC_SUCCESS) rc = orc_misc_resample(D, eps_t, q, eps_t * scl * (double)nskip, q2);
+        if (rc == ORC_SUCCESS) {
+            const double w0 = 0.25 + scl, w1 = 0.25 - scl;
+            for (size_t i = 0, is = 0; is < D_eff; is += 2, i += nskip) {
+                out[is] = w0 * q1[i] + w1 * q2[i];
+                out[is + 1] = w1 * q1[i] + w0 * q2[i];
+            }
+        }
+        free(q1);
+        free(q2);
+    }
+    if (rc != ORC_SUCCESS) { free(out); return rc; }
+    *q_pre = out;
+    *Dsub_ptr = Dsub;
+    first_last[0] = 0;
+    first_last[1] = (Dsub - 1) * nskip;
+    return ORC_SUCCESS;
+}
+
+/* fnft_nsev.c:133-453, contspec-only subset: preprocessing (:272), base call (:312), Richardson
+ * extrapolation (:316-406): a second transform of every other sample and
+ * (s*fine - coarse)/(s - 1), s = (eps_sub/eps)^order, order = 2 for the 2SPLIT schemes and 4 for
+ * 4SPLIT4A/B (fnft__akns_discretization.c:157-192), where |xi| < 0.9*pi/(2*eps_sub). */
+int orc_fnft_nsev_ex(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
+                     const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag,
+                     int richardson_flag)
+{
+    if (D < 2 || !q || !T || !(T[0] < T[1])) return ORC_EC_INVALID_ARGUMENT;
+    if (contspec && (!XI || !(XI[0] < XI[1]))) return ORC_EC_INVALID_ARGUMENT;
+    if (abs(kappa) != 1) return ORC_EC_INVALID_ARGUMENT;
+    if (orc_nse_to_akns(nse_disc) < 0) return ORC_EC_INVALID_ARGUMENT;
+    const size_t ups = orc_nse_upsampling(nse_disc);
+    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
+    size_t Dsub = D, fl[2];
+    orc_cplx *q_pre = NULL;
+    int rc = orc_nse_preprocess(D, q, eps_t, &Dsub, &q_pre, fl, nse_disc);
+    if (rc != ORC_SUCCESS) return -abs(rc);
+    rc = orc_nsev_base(D * ups, q_pre, T, M, contspec, XI, kappa, nse_disc, cstype, normalization_flag);
+    free(q_pre);
+    if (rc != ORC_SUCCESS || !richardson_flag || !contspec || M == 0) return rc;
+    Dsub = D / 2; /* CEIL(D/2) on integers, fnft_nsev.c:376 */
+    orc_cplx *qsub = NULL;
+    rc = orc_nse_preprocess(D, q, eps_t, &Dsub, &qsub, fl, nse_disc);
+    if (rc != ORC_SUCCESS) return -abs(rc);
     const size_t cs_len = M * (cstype == ORC_CS_RHO ? 1 : (cstype == ORC_CS_AB ? 2 : 3));
-    orc_cplx *qsub = malloc(Dsub * sizeof(orc_cplx)), *csub = malloc(cs_len * sizeof(orc_cplx));
-    if (!qsub || !csub) { free(qsub); free(csub); return ORC_EC_NOMEM; }
-    for (size_t i = 0; i < Dsub; i++) qsub[i] = q[i * nskip];
-    const double Tsub[2] = {T[0], T[0] + (double)((Dsub - 1) * nskip) * eps_t};
+    orc_cplx *csub = malloc(cs_len * sizeof(orc_cplx));
+    if (!csub) { free(qsub); return ORC_EC_NOMEM; }
+    const double Tsub[2] = {T[0] + (double)fl[0] * eps_t, T[0] + (double)fl[1] * eps_t};
     const double eps_sub = (Tsub[1] - Tsub[0]) / (double)(Dsub - 1);
-    rc = orc_nsev_base(Dsub, qsub, Tsub, M, csub, XI, kappa, nse_disc, cstype, normalization_flag);
+    rc = orc_nsev_base(Dsub * ups, qsub, Tsub, M, csub, XI, kappa, nse_disc, cstype, normalization_flag);
     if (rc == ORC_SUCCESS) {
-        const double scl_num = pow(eps_sub / eps_t, 2.0), scl_den = scl_num - 1.0;
+        const double order = (ups == 2) ? 4.0 : 2.0;
+        const double scl_num = pow(eps_sub / eps_t, order), scl_den = scl_num - 1.0;
         const double dxi = (XI[1] - XI[0]) / (double)(M - 1);
         const double pi = acos(-1.0);
         for (size_t i = 0; i < M; i++)
@@ -808,9 +935,10 @@ int orc_fnft_nsev_ex(size_t D, const orc_cplx *q, const double *T, size_t M, orc
 int orc_fnft_nsev(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
                   const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag)
 {
-    return orc_nsev_base(D, q, T, M, contspec, XI, kappa, nse_disc, cstype, normalization_flag);
+    return orc_fnft_nsev_ex(D, q, T, M, contspec, XI, kappa, nse_disc, cstype, normalization_flag, 0);
 }
 
+/* D = number of preprocessed samples (D_given * upsampling) */
 static int orc_nsev_base(size_t D, const orc_cplx *q, const double *T, size_t M, orc_cplx *contspec,
                          const double *XI, int kappa, int nse_disc, int cstype, int normalization_flag)
 {
@@ -819,7 +947,7 @@ static int orc_nsev_base(size_t D, const orc_cplx *q, const double *T, size_t M,
     if (abs(kappa) != 1) return ORC_EC_INVALID_ARGUMENT;
     const size_t numel = orc_nse_fscatter_numel(D, nse_disc);
     if (numel == 0) return ORC_EC_INVALID_ARGUMENT;
-    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
+    const double eps_t = (T[1] - T[0]) / (double)(D / orc_nse_upsampling(nse_disc) - 1);
     orc_cplx *tm = malloc(numel * sizeof(orc_cplx));
     if (!tm) return ORC_EC_NOMEM;
     size_t deg = 0;

@@ -46,7 +46,8 @@ enum orc_akns_disc {
     ORC_AKNS_2SPLIT2_MODAL = 0, ORC_AKNS_2SPLIT1A, ORC_AKNS_2SPLIT1B, ORC_AKNS_2SPLIT2A,
     ORC_AKNS_2SPLIT2B, ORC_AKNS_2SPLIT2S, ORC_AKNS_2SPLIT3A, ORC_AKNS_2SPLIT3B, ORC_AKNS_2SPLIT3S,
     ORC_AKNS_2SPLIT4A, ORC_AKNS_2SPLIT4B, ORC_AKNS_2SPLIT5A, ORC_AKNS_2SPLIT5B, ORC_AKNS_2SPLIT6A,
-    ORC_AKNS_2SPLIT6B, ORC_AKNS_2SPLIT7A, ORC_AKNS_2SPLIT7B, ORC_AKNS_2SPLIT8A, ORC_AKNS_2SPLIT8B
+    ORC_AKNS_2SPLIT6B, ORC_AKNS_2SPLIT7A, ORC_AKNS_2SPLIT7B, ORC_AKNS_2SPLIT8A, ORC_AKNS_2SPLIT8B,
+    ORC_AKNS_BO, ORC_AKNS_4SPLIT4A, ORC_AKNS_4SPLIT4B
 };
 
 /* contspec_type values of fnft_nsev_cstype_t (include/fnft_nsev.h:130-134). */
@@ -56,6 +57,14 @@ enum orc_cstype { ORC_CS_RHO = 0, ORC_CS_AB = 1, ORC_CS_BOTH = 2 };
 size_t orc_next_fast_size(size_t n);
 /* out[k] = sum_n in[n] exp(sign*2*pi*i*n*k/len), sign = -1 forward, +1 inverse, no 1/len. */
 int orc_fft(size_t len, const orc_cplx *in, orc_cplx *out, int sign);
+/* any length (Bluestein when len has prime factors other than 2, 3, 5) */
+int orc_dft(size_t len, const orc_cplx *in, orc_cplx *out, int sign);
+/* fnft__misc.c:326-407 */
+int orc_misc_resample(size_t D, double eps_t, const orc_cplx *q, double delta, orc_cplx *q_new);
+/* fnft__nse_discretization.c:386-656 for the splitting schemes: q_pre has Dsub*upsampling entries */
+int orc_nse_preprocess(size_t D, const orc_cplx *q, double eps_t, size_t *Dsub_ptr, orc_cplx **q_pre,
+                       size_t *first_last, int nse_disc);
+size_t orc_nse_upsampling(int nse_disc);
 
 /* --- polynomial helpers --- */
 /* fnft__poly_eval.c:25-53: z[i] <- p(z[i]), coefficients highest power first. */

@@ -21,7 +21,7 @@ AKNS_DISC = {
     "2SPLIT2_MODAL": 0, "2SPLIT1A": 1, "2SPLIT1B": 2, "2SPLIT2A": 3, "2SPLIT2B": 4, "2SPLIT2S": 5,
     "2SPLIT3A": 6, "2SPLIT3B": 7, "2SPLIT3S": 8, "2SPLIT4A": 9, "2SPLIT4B": 10,
     "2SPLIT5A": 11, "2SPLIT5B": 12, "2SPLIT6A": 13, "2SPLIT6B": 14, "2SPLIT7A": 15, "2SPLIT7B": 16,
-    "2SPLIT8A": 17, "2SPLIT8B": 18,
+    "2SPLIT8A": 17, "2SPLIT8B": 18, "4SPLIT4A": 20, "4SPLIT4B": 21,
 }
 CSTYPE = {"RHO": 0, "AB": 1, "BOTH": 2}
 

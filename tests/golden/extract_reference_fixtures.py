@@ -54,6 +54,62 @@ def array_init(src, name):
     return [ceval(x) for x in body.split(",") if x.strip()]
 
 
+def walk_stages(src):
+    """Replays the body of one test/fnft_nsev/*.c file statement by statement -- D and DN updates,
+    bound arrays and their rescaling loops, the Richardson flag -- and records every call of the
+    harness nsev_testcases_test_fnft(tc, <D>, <bounds>, &opts) as
+    {"D": .., "richardson": 0/1, "bounds": [rho, a, b]}."""
+    env = {"D": None, "DN": None}
+    arrays = {}
+    rich = 0
+    stages = []
+    inf = float("inf")
+
+    def num(expr):
+        expr = expr.replace("(REAL)", "").replace("POW", "pow").replace("INFINITY", "inf").replace("FNFT_INF", "inf")
+        return float(eval(expr, {"__builtins__": {}, "pow": pow, "inf": inf},
+                          {k: v for k, v in env.items() if v is not None}))
+
+    body = src[src.index("main"):] if "main" in src else src
+    # a "for (i=0; i<6; i++) X;" loop is one statement applying X to every entry
+    tok = re.compile(
+        r"(?P<arr>REAL\s+(?P<an>error_bounds\w*)\s*\[\s*6\s*\]\s*=\s*\{(?P<av>.*?)\}\s*;)"
+        r"|(?P<decl>UINT\s+(?P<dn>D|DN)\s*=\s*(?P<dv>[^;]+);)"
+        r"|(?P<loop>for\s*\([^)]*\)\s*(?P<ln>error_bounds\w*)\s*\[\s*i\s*\]\s*(?P<lo>[*/])=\s*(?P<lv>[^;]+);)"
+        r"|(?P<one>(?P<on>error_bounds\w*)\s*\[\s*(?P<oi>\d+)\s*\]\s*(?P<oo>[*/])=\s*(?P<ov>[^;]+);)"
+        r"|(?P<dop>\bD\s*(?P<do>[*/+-])=\s*(?P<dval>[^;]+);)"
+        r"|(?P<dset>\bD\s*=\s*(?P<dsv>[^;=]+);)"
+        r"|(?P<rich>opts\.richardson_extrapolation_flag\s*=\s*(?P<rv>\d)\s*;)"
+        r"|(?P<call>nsev_testcases_test_fnft\s*\(\s*tc\s*,\s*(?P<cd>[^,]+),\s*(?P<ca>\w+)\s*,)",
+        flags=re.S)
+    for m in tok.finditer(body):
+        if m.group("arr"):
+            arrays[m.group("an")] = [num(x.strip()) for x in m.group("av").split(",") if x.strip()]
+        elif m.group("decl"):
+            env[m.group("dn")] = int(num(m.group("dv")))
+        elif m.group("loop"):
+            f = num(m.group("lv"))
+            a = arrays[m.group("ln")]
+            arrays[m.group("ln")] = [x * f if m.group("lo") == "*" else x / f for x in a]
+        elif m.group("one"):
+            f = num(m.group("ov"))
+            a = arrays[m.group("on")]
+            i = int(m.group("oi"))
+            a[i] = a[i] * f if m.group("oo") == "*" else a[i] / f
+        elif m.group("dop"):
+            v = num(m.group("dval"))
+            op = m.group("do")
+            env["D"] = int({"*": env["D"] * v, "/": env["D"] / v, "+": env["D"] + v, "-": env["D"] - v}[op])
+        elif m.group("dset"):
+            env["D"] = int(num(m.group("dsv")))
+        elif m.group("rich"):
+            rich = int(m.group("rv"))
+        elif m.group("call"):
+            stages.append({"D": int(num(m.group("cd"))), "richardson": rich,
+                           "bounds": list(arrays[m.group("ca")][:3])})
+    return stages
+
+
 def main():
     out = {"_generated_by": "tests/golden/extract_reference_fixtures.py",
            "_reference": "IgorChekhovskoy/FNFT @ 2025-01-27 (FNFT 0.4.1)"}
@@ -186,6 +242,7 @@ def main():
             vals_re = [float(eval(x.strip(), {"__builtins__": {}, "float": float, "INFINITY": float("inf")}, {}))
                        for x in mre.group(1).split(",") if x.strip()]
         bounds.append({
+            "stages": walk_stages(src),
             "error_bounds_RE": vals_re[:3] if vals_re else None,
             "file": fn, "testcase": mtc.group(1),
             "discretization": mdisc.group(1) if mdisc else "2SPLIT4B",

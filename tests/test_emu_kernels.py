@@ -102,7 +102,7 @@ def test_tree_vs_direct(emu, deg, n):
     assert S.rel_err((res * 2.0 ** W).ravel(), ref.ravel()) < (1e-13 if n < 100 else 5e-12)
 
 
-@pytest.mark.parametrize("scheme", sorted(AKNS_DISC))
+@pytest.mark.parametrize("scheme", [s for s in sorted(AKNS_DISC) if s.startswith("2SPLIT")])
 def test_akns_fscatter_golden(emu, oracle, fixtures, scheme):
     fx = fixtures["akns_fscatter"]["schemes"][scheme]
     q, r, z = S.akns_test_signal(fx["D"])

@@ -74,7 +74,7 @@ def test_poly_chirpz_golden(oracle, fixtures):
         assert S.rel_err(out, S.l2c(fx[key])) <= fx["tol_rel_l1"]
 
 
-@pytest.mark.parametrize("scheme", sorted(AKNS_DISC))
+@pytest.mark.parametrize("scheme", [s for s in sorted(AKNS_DISC) if s.startswith("2SPLIT")])
 @pytest.mark.parametrize("normalize", [False, True])
 def test_akns_fscatter_golden(oracle, fixtures, scheme, normalize):
     fx = fixtures["akns_fscatter"]["schemes"][scheme]
@@ -130,37 +130,22 @@ def _bound_cases(fixtures_path="tests/golden/reference_fixtures.json"):
 
 @pytest.mark.parametrize("b", _bound_cases())
 def test_fnft_nsev_analytic_bounds(oracle, fixtures, b):
-    """fnft__nsev_testcases.c:711-822 run at D, D+1, D-1 and at 2D with the test's own rescaled
-    bounds (order-of-convergence check, test/fnft_nsev/*.c)."""
-    D = b["D"]
-    stages = [(D, b["error_bounds"]), (D + 1, b["error_bounds"]), (D - 1, b["error_bounds"])]
-    if b.get("error_bounds_2D"):
-        stages.append((2 * D, b["error_bounds_2D"]))
-    for DD, bounds in stages:
-        errs = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], DD)
-        for e, bound in zip(errs, bounds):
+    """fnft__nsev_testcases.c:711-822 driven exactly as test/fnft_nsev/<file>.c drives it: every
+    harness call of the file (D, D+1, D-1, 2D with rescaled bounds, and the Richardson stages
+    where the file has them) is one entry of b["stages"]."""
+    assert b["stages"]
+    for st in b["stages"]:
+        errs = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], st["D"],
+                            richardson=bool(st["richardson"]))
+        for e, bound in zip(errs, st["bounds"]):
             if np.isfinite(bound):
-                assert e <= bound, (DD, errs, b)
+                assert e <= bound, (st, errs, b["file"])
 
 
-def _re_cases():
-    return [c for c in _bound_cases() if c.values[0].get("error_bounds_RE")]
-
-
-@pytest.mark.parametrize("b", _re_cases())
-def test_fnft_nsev_richardson_bounds(oracle, fixtures, b):
-    """test/fnft_nsev/fnft_nsev_test_sech_*_2split4A.c: richardson_extrapolation_flag = 1 with
-    error_bounds_RE at D and error_bounds_RE/16 at 2D (fourth order after extrapolation)."""
-    D = b["D"]
-    for DD, scl in ((D, 1.0), (2 * D, 1.0 / 16.0)):
-        errs = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], DD, richardson=True)
-        for e, bound in zip(errs, b["error_bounds_RE"]):
-            if np.isfinite(bound):
-                assert e <= bound * scl, (DD, errs, b)
-    # and the extrapolation actually changes (improves) the plain result
-    plain = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], D)
-    rich = _nsev_errors(oracle, fixtures, b["testcase"], b["discretization"], D, richardson=True)
-    assert rich[0] < plain[0]
+def test_richardson_improves(oracle, fixtures):
+    plain = _nsev_errors(oracle, fixtures, "SECH_FOCUSING", "2SPLIT4A", 4096)
+    rich = _nsev_errors(oracle, fixtures, "SECH_FOCUSING", "2SPLIT4A", 4096, richardson=True)
+    assert rich[0] < 0.1 * plain[0]
 
 
 def test_modal_defocusing_step_check(oracle):
