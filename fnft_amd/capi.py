@@ -63,7 +63,7 @@ EXPORTED = [
     "fnft_errwarn_getprintf", "fnft__poly_fmult2x2_numel", "fnft__poly_fmult2x2",
     "fnft_amd_poly_chirpz", "fnft__poly_chirpz", "fnft__akns_fscatter_numel", "fnft__akns_fscatter",
     "fnft__nse_fscatter_numel", "fnft__nse_fscatter", "fnft_amd_device_count",
-    "fnft_amd_last_error", "fnft_amd_plan_create", "fnft_amd_plan_destroy",
+    "fnft_amd_last_error", "fnft_amd_plan_create", "fnft_amd_plan_create_sub", "fnft_amd_plan_destroy",
     "fnft_amd_plan_workspace_bytes", "fnft_amd_nsev_contspec_device", "fnft_amd_plan_finish",
     "fnft_amd_plan_last_ms", "fnft_amd_plan_set_timing", "fnft_amd_plan_get_transfer_matrix",
 ]
@@ -117,6 +117,8 @@ def load(path=None):
     L.fnft_amd_last_error.restype = C.c_char_p
     L.fnft_amd_plan_create.restype = i32
     L.fnft_amd_plan_create.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int]
+    L.fnft_amd_plan_create_sub.restype = i32
+    L.fnft_amd_plan_create_sub.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int, sz]
     L.fnft_amd_plan_destroy.restype = None
     L.fnft_amd_plan_destroy.argtypes = [vp]
     L.fnft_amd_plan_workspace_bytes.restype = sz
@@ -249,13 +251,13 @@ def nse_fscatter(q, eps_t, kappa, discretization, normalize=True):
 class Plan:
     """fnft_amd_plan_t: `batch` signals of D samples, M spectral points, one discretization."""
 
-    def __init__(self, D, M, batch=1, discretization="2SPLIT2_MODAL", device=0):
+    def __init__(self, D, M, batch=1, discretization="2SPLIT2_MODAL", device=0, nskip=1):
         self.L = load()
         self.D, self.M, self.batch = int(D), int(M), int(batch)
         self.disc = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
         self.h = C.c_void_p()
-        rc = self.L.fnft_amd_plan_create(C.byref(self.h), self.D, self.M, self.batch, self.disc,
-                                         int(device))
+        rc = self.L.fnft_amd_plan_create_sub(C.byref(self.h), self.D, self.M, self.batch, self.disc,
+                                             int(device), int(nskip))
         if rc != FNFT_SUCCESS:
             raise RuntimeError("fnft_amd_plan_create rc=%d (%s)" % (rc, last_error()))
 

@@ -23,7 +23,7 @@
 FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const FNFT_REAL *T,
                                       FNFT_UINT M, FNFT_COMPLEX *contspec, const FNFT_REAL *XI,
                                       FNFT_INT kappa, int discretization, int contspec_type,
-                                      FNFT_INT normalization_flag);
+                                      FNFT_INT normalization_flag, FNFT_UINT nskip);
 
 /* ---- error / warning text, src/fnft_errwarn.c:28-60 ---------------------------------------- */
 static FNFT_INT default_printf(const char *format, ...)
@@ -186,10 +186,12 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
     case fnft_nse_discretization_2SPLIT7B:
     case fnft_nse_discretization_2SPLIT8A:
     case fnft_nse_discretization_2SPLIT8B:
+    case fnft_nse_discretization_4SPLIT4A:
+    case fnft_nse_discretization_4SPLIT4B:
         break;
     default:
         return E_NOT_YET_IMPLEMENTED(discretization,
-                                     "GPU path covers the 2SPLIT schemes (orders 1 to 8).");
+                                     "GPU path covers the fast (polynomial) discretizations.");
     }
     if (kappa == +1 && bound_states != NULL)
         return E_NOT_YET_IMPLEMENTED(bound_states, "Pass bound_states = NULL for the continuous spectrum.");
@@ -204,7 +206,7 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
 
     ret_code = fnft_amd__nsev_contspec_host(D, q, T, (contspec != NULL) ? M : 0, contspec, XI, kappa,
                                             (int)opts->discretization, (int)opts->contspec_type,
-                                            opts->normalization_flag);
+                                            opts->normalization_flag, 1);
     if (ret_code != FNFT_SUCCESS) {
         if (ret_code == FNFT_EC_OTHER || ret_code == FNFT_EC_NOMEM)
             return raise(ret_code, __func__, __LINE__, "GPU runtime failure (see fnft_amd_last_error()).");
@@ -213,8 +215,10 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
 
     /* Richardson extrapolation of the continuous spectrum, src/fnft_nsev.c:316-406: second
      * transform of every other sample (subsampling rule of
-     * src/private/fnft__nse_discretization.c:426-473), method order 2 for all 2SPLIT schemes
-     * (src/private/fnft__akns_discretization.c:157-192). */
+     * src/private/fnft__nse_discretization.c:426-473), method order 2 for the 2SPLIT schemes and
+     * 4 for 4SPLIT4A/B (src/private/fnft__akns_discretization.c:157-192).  For 4SPLIT4A/B the coarse
+     * transform still resamples the full signal (:474-503), so the device plan gets all D samples
+     * and the skip count. */
     if (opts->richardson_extrapolation_flag == 1 && contspec != NULL && M > 0) {
         const FNFT_REAL eps_t = (T[1] - T[0]) / (D - 1);
         const int cst = (int)opts->contspec_type;
@@ -234,10 +238,17 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
         for (FNFT_UINT i = 0; i < Dsub; i++) qsub[i] = q[i * nskip];
         const FNFT_REAL Tsub[2] = {T[0], T[0] + ((Dsub - 1) * nskip) * eps_t};
         const FNFT_REAL eps_t_sub = (Tsub[1] - Tsub[0]) / (Dsub - 1);
-        ret_code = fnft_amd__nsev_contspec_host(Dsub, qsub, Tsub, M, csub, XI, kappa,
-                                                (int)opts->discretization, cst, opts->normalization_flag);
+        const int four = opts->discretization == fnft_nse_discretization_4SPLIT4A
+                         || opts->discretization == fnft_nse_discretization_4SPLIT4B;
+        if (four)
+            ret_code = fnft_amd__nsev_contspec_host(D, q, T, M, csub, XI, kappa, (int)opts->discretization,
+                                                    cst, opts->normalization_flag, nskip);
+        else
+            ret_code = fnft_amd__nsev_contspec_host(Dsub, qsub, Tsub, M, csub, XI, kappa,
+                                                    (int)opts->discretization, cst,
+                                                    opts->normalization_flag, 1);
         if (ret_code == FNFT_SUCCESS) {
-            const FNFT_REAL scl_num = pow(eps_t_sub / eps_t, 2.0);
+            const FNFT_REAL scl_num = pow(eps_t_sub / eps_t, four ? 4.0 : 2.0);
             const FNFT_REAL scl_den = scl_num - 1.0;
             const FNFT_REAL dxi = (XI[1] - XI[0]) / (M - 1);
             const FNFT_REAL pi = acos(-1.0);

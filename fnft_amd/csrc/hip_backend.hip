@@ -138,16 +138,27 @@ const char *fnft_amd_last_error(void) { return g_last_error.c_str(); }
 FNFT_INT fnft_amd_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
                               fnft_nse_discretization_t discretization, int device)
 {
-    if (!plan || D < 2 || batch < 1) return FNFT_EC_INVALID_ARGUMENT;
+    return fnft_amd_plan_create_sub(plan, D, M, batch, discretization, device, 1);
+}
+
+FNFT_INT fnft_amd_plan_create_sub(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
+                                  fnft_nse_discretization_t discretization, int device, FNFT_UINT nskip)
+{
+    if (!plan || D < 2 || batch < 1 || nskip < 1) return FNFT_EC_INVALID_ARGUMENT;
     const int akns = nft_nse_to_akns((int)discretization);
     if (akns < 0) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    const int ups = nft_nse_upsampling((int)discretization);
+    if (ups == 1 && nskip != 1) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    if (ups == 2 && D <= 2) return FNFT_EC_INVALID_ARGUMENT;   // fnft__misc.c:331-332
     if (!ensure_device(device)) return FNFT_EC_OTHER;
     fnft_amd_plan *P = new (std::nothrow) fnft_amd_plan();
     if (!P) return FNFT_EC_NOMEM;
     P->device = device;
     P->nse_disc = (int)discretization;
-    P->pl = new (std::nothrow) Plan(P->be, D, M, batch, akns, nft_akns_degree(akns));
+    const size_t Dtree = (ups == 1) ? (size_t)D : 2 * Plan::sub_count((size_t)D, (size_t)nskip);
+    P->pl = new (std::nothrow) Plan(P->be, Dtree, M, batch, akns, nft_akns_degree(akns));
     if (!P->pl) { delete P; return FNFT_EC_NOMEM; }
+    P->pl->set_front((size_t)D, (size_t)nskip, ups);
     if (const char *dbg = getenv("FNFT_AMD_DBG")) P->pl->dbg_flags = atoi(dbg);
     const int rc = P->pl->init();
     if (rc != NFT_SUCCESS || P->be.failed) {
@@ -205,14 +216,14 @@ FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, v
     Plan &pl = *plan->pl;
     plan->be.stream = (hipStream_t)stream;
     plan->be.failed = false;
-    const double eps_t = (T[1] - T[0]) / (double)(pl.D - 1);
     plan->be.mark(0);
-    int rc = pl.run_coeffs(d_q, nullptr, eps_t, kappa);
+    double Tsub[2];
+    int rc = pl.run_front(d_q, T, kappa, Tsub);
     if (rc == NFT_SUCCESS) rc = pl.run_tree();
     plan->be.mark(1);
     if (rc == NFT_SUCCESS && d_contspec && pl.M > 0) {
         Plan::Contspec cs;
-        cs.T[0] = T[0]; cs.T[1] = T[1]; cs.XI[0] = XI[0]; cs.XI[1] = XI[1];
+        cs.T[0] = Tsub[0]; cs.T[1] = Tsub[1]; cs.XI[0] = XI[0]; cs.XI[1] = XI[1];
         cs.nse_disc = plan->nse_disc;
         cs.cstype = cst;
         cs.normalization_flag = normalization_flag;
@@ -323,27 +334,29 @@ FNFT_INT fnft__nse_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q, cons
 }
 
 // ---- internal entry used by the C driver (fnft_nsev_host.c) ------------------------------------
-// Host buffers in, host buffers out; plans are cached per (D, M, discretization).
+// Host buffers in, host buffers out; plans are cached per (D, M, discretization, nskip).
+// nskip > 1 (4SPLIT4A/B only): the transform of every nskip-th step of the D samples, as
+// fnft__nse_discretization_preprocess_signal forms it for Richardson extrapolation.
 FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const FNFT_REAL *T,
                                       FNFT_UINT M, FNFT_COMPLEX *contspec, const FNFT_REAL *XI,
                                       FNFT_INT kappa, int discretization, int contspec_type,
-                                      FNFT_INT normalization_flag)
+                                      FNFT_INT normalization_flag, FNFT_UINT nskip)
 {
     static std::mutex cache_mtx;
-    static std::map<std::tuple<size_t, size_t, int>, fnft_amd_plan *> cache;
+    static std::map<std::tuple<size_t, size_t, int, size_t>, fnft_amd_plan *> cache;
     if (!ensure_device(0)) return FNFT_EC_OTHER;
     fnft_amd_plan *P = nullptr;
     {
         std::lock_guard<std::mutex> lk(cache_mtx);
-        auto key = std::make_tuple((size_t)D, (size_t)M, discretization);
+        auto key = std::make_tuple((size_t)D, (size_t)M, discretization, (size_t)nskip);
         auto it = cache.find(key);
         if (it == cache.end()) {
             if (cache.size() >= 4) {  // keep the workspace footprint bounded
                 for (auto &kv : cache) fnft_amd_plan_destroy(kv.second);
                 cache.clear();
             }
-            const FNFT_INT rc = fnft_amd_plan_create(&P, D, M, 1,
-                                                     (fnft_nse_discretization_t)discretization, 0);
+            const FNFT_INT rc = fnft_amd_plan_create_sub(&P, D, M, 1,
+                                                         (fnft_nse_discretization_t)discretization, 0, nskip);
             if (rc != FNFT_SUCCESS) return rc;
             cache[key] = P;
         } else {

@@ -24,6 +24,18 @@ struct KCoeffsProg {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_coeffs_prog(p); }
 };
+struct KResamplePhase {
+    using Params = ResampleParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_resample_phase(p); }
+};
+struct KResampleCombine {
+    using Params = ResampleParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_resample_combine(p); }
+};
 template <int DEG> struct LeafCfg {
     static constexpr int SPT = (DEG == 1) ? 8 : (DEG == 2 ? 4 : 2);
 };

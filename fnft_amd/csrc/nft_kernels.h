@@ -1345,6 +1345,11 @@ struct ChirpParams {
     int cstype;          // fnft_nsev_cstype_t ordinal, or -1: raw H values to Hbuf
     int use_W;
     int jobs_per_group;  // row step: jobs handled by one workgroup (grid.y = ceil(jobs/this))
+    // DFT mode (band-limited resampling, fnft__misc.c:326-407): A = 1, W = exp(dft_sign*2*pi*i/dft_len);
+    // the chirp W^(n^2/2) = cis(dft_sign*pi*(n^2 mod 2*dft_len)/dft_len) is formed from the integer
+    // residue, and poly holds coefficients in ascending order (x[n] multiplies z^n)
+    long long dft_len;   // 0: off
+    int dft_sign;
 };
 
 // exp((xr + i*xi)) with a real multiplier folded in: returns exp(t*lr) * cis(t*li)
@@ -1372,9 +1377,26 @@ FA_DEV cplx cpow_real2(const double la[2], double ta, const double lw[2], double
     return cmake(mag * c, mag * s);
 }
 
+// W^(half * n^2), half = +-0.5
+FA_DEV cplx chirp_w(const ChirpParams &C, long long n, double half)
+{
+    if (C.dft_len > 0) {
+        const unsigned long long r = ((unsigned long long)n * (unsigned long long)n)
+                                     % (2ull * (unsigned long long)C.dft_len);
+        double s, c;
+        fa_sincos(3.141592653589793238462643383279502884 * ((double)r / (double)C.dft_len), &s, &c);
+        const double sg = (half > 0.0 ? 1.0 : -1.0) * (double)C.dft_sign;
+        return cmake(c, sg * s);
+    }
+    const double dn = (double)n;
+    return cpow_real(C.logW, half * dn * dn);
+}
+
 FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k)
 {
     // coefficient k (highest power first) of polynomial `slot` of signal b
+    if (C.poly && C.dft_len > 0)
+        return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)(C.deg - k)];
     if (C.poly) return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)k];
     return stored_coef(C.body, C.tail, C.plane, C.deg_tot, C.deg, C.batch, C.ne, C.entry[slot], b, k)
            * C.scale[b];
@@ -1403,14 +1425,12 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_fwd(const C
         if (job < njobs) {
             if (n < Np) {  // :68-69  p[deg-n] * A^-n * W^(n^2/2)
                 const cplx pc = chirp_poly_coef(C, job / C.npoly, job % C.npoly, C.deg - n);
-                val = pc * cpow_real2(C.logA, -dn, C.logW, 0.5 * dn * dn);
+                val = (C.dft_len > 0) ? pc * chirp_w(C, n, 0.5)
+                                      : pc * cpow_real2(C.logA, -dn, C.logW, 0.5 * dn * dn);
             }
         } else {  // :76-82
-            if (n < C.M) val = cpow_real(C.logW, -0.5 * dn * dn);
-            else if (n > Lc - Np) {
-                const double dm = (double)(Lc - n);
-                val = cpow_real(C.logW, -0.5 * dm * dm);
-            }
+            if (n < C.M) val = chirp_w(C, n, -0.5);
+            else if (n > Lc - Np) val = chirp_w(C, Lc - n, -0.5);
         }
         x[i] = val;
     }
@@ -1509,8 +1529,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const C
         const long long m = (long long)n1 * C.N2 + n2;
         if (m >= C.M) continue;
         {   // :94-95  result[m] = W^(m^2/2) * V[m] / L
-            const double dm = (double)m;
-            const cplx cw = cpow_real(C.logW, 0.5 * dm * dm);
+            const cplx cw = chirp_w(C, m, 0.5);
             H[0][i] = H[0][i] * cw;
             H[1][i] = H[1][i] * cw;
         }
@@ -1545,4 +1564,48 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const C
             out[off + C.M + m] = (h21 * scale) * cmake(co, s);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4SPLIT4A/B front end (fnft__nse_discretization.c:474-503): two band-limited resamplings of the
+// signal at -/+ delta (fnft__misc.c:326-407: DFT, phase ramp, inverse DFT -- the DFTs are chirp
+// transforms in DFT mode, any length) and their weighted combination, two samples per step.
+// ---------------------------------------------------------------------------------------------
+struct ResampleParams {
+    const cplx *X;     // batch * Din: spectrum of the signal
+    cplx *X12;         // batch * 2 * Din: spectra of the two shifted copies
+    const cplx *Q12;   // batch * 2 * Din: the two shifted copies times Din (unnormalised inverse DFT)
+    cplx *qpre;        // batch * 2 * Dsub
+    long long Din, Dsub, nskip;
+    int batch;
+    double delta_over_span;   // delta / (Din * eps_t)
+    double w0, w1;            // 0.25 + sqrt(3)/6, 0.25 - sqrt(3)/6
+};
+
+FA_DEV void body_resample_phase(const ResampleParams &P)
+{
+    const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (gid >= (long long)P.batch * P.Din) return;
+    const long long b = gid / P.Din, i = gid % P.Din;
+    // freq[i]*delta, :383-390: i/(D eps) below D/2, (i - D)/(D eps) from D/2 on
+    const double f = (i < P.Din / 2) ? (double)i : (double)i - (double)P.Din;
+    double s, c;
+    fa_sincos(2.0 * 3.141592653589793238462643383279502884 * (P.delta_over_span * f), &s, &c);
+    const cplx x = P.X[gid];
+    P.X12[(size_t)(2 * b) * P.Din + i] = x * cmake(c, -s);      // shift by -delta
+    P.X12[(size_t)(2 * b + 1) * P.Din + i] = x * cmake(c, s);   // shift by +delta
+}
+
+FA_DEV void body_resample_combine(const ResampleParams &P)
+{
+    const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (gid >= (long long)P.batch * P.Dsub) return;
+    const long long b = gid / P.Dsub, is = gid % P.Dsub;
+    const long long i = is * P.nskip;
+    const double inv = 1.0 / (double)P.Din;
+    const cplx q1 = P.Q12[(size_t)(2 * b) * P.Din + i] * inv;
+    const cplx q2 = P.Q12[(size_t)(2 * b + 1) * P.Din + i] * inv;
+    cplx *out = P.qpre + (size_t)b * 2 * P.Dsub + 2 * is;
+    out[0] = q1 * P.w0 + q2 * P.w1;
+    out[1] = q1 * P.w1 + q2 * P.w0;
 }

@@ -73,9 +73,16 @@ inline int nft_nse_to_akns(int nse_disc)
     case 11: return 10;  // 2SPLIT4B
     case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19:
         return nse_disc - 1;   // 2SPLIT5A .. 2SPLIT8B -> akns 11 .. 18
+    case 20: return 9;   // 4SPLIT4A: per-sample formulas of 2SPLIT4A (fnft__akns_fscatter.c:362-363)
+    case 21: return 10;  // 4SPLIT4B: ... of 2SPLIT4B (:402-403)
     default: return -1;
     }
 }
+
+// fnft__akns_discretization.c:114-152: preprocessed samples per step
+inline int nft_nse_upsampling(int nse_disc) { return (nse_disc == 20 || nse_disc == 21) ? 2 : 1; }
+// fnft__akns_discretization.c:157-192: order used by Richardson extrapolation
+inline int nft_nse_method_order(int nse_disc) { return (nse_disc == 20 || nse_disc == 21) ? 4 : 2; }
 
 // log of a complex number through libm's clog -- the routine glibc's cpow() (which the reference
 // calls for every chirp factor, src/private/fnft__poly_chirpz.c:69,77,81,95) is built on.  It keeps
@@ -122,6 +129,12 @@ public:
     int *prog_ptr = nullptr;
     unsigned char *prog_fac = nullptr;
     int prog_nB = 0, prog_maxf = 0;
+    // 4SPLIT4A/B front end (set_front): Din input samples per signal, every nskip-th step kept,
+    // ups preprocessed samples per kept step; D = ups * Dsub matrices enter the tree
+    size_t Din = 0, nskip = 1;
+    int ups = 1;
+    cplx *qpre = nullptr, *rsX = nullptr, *rsX12 = nullptr, *rsQ12 = nullptr, *rsY = nullptr, *rsV = nullptr;
+    size_t Lr = 0;
     cplx *Y = nullptr, *Z = nullptr, *Z2 = nullptr;   // Z ping-pongs when spectral doubling is on
     cplx *chY = nullptr, *chV = nullptr, *chH = nullptr;
     cplx *tm_out = nullptr;
@@ -149,6 +162,11 @@ public:
         plane = n0 * (size_t)deg0;
     }
 
+    // fnft__nse_discretization.c:419-427: samples kept when every nskip-th of Din is used
+    static size_t sub_count(size_t Din_, size_t nskip_) { return (size_t)std::llround((double)Din_ / (double)nskip_); }
+    // call before init(): this plan was constructed with D = ups_ * sub_count(Din_, nskip_)
+    void set_front(size_t Din_, size_t nskip_, int ups_) { Din = Din_; nskip = nskip_; ups = ups_; }
+
     template <class T> bool alloc(T *&p, size_t count)
     {
         const size_t b = count * sizeof(T);
@@ -175,6 +193,9 @@ public:
     int init()
     {
         if (D < 1 || batch < 1 || deg0 < 1) return NFT_EC_INVALID_ARGUMENT;
+        if (Din == 0) Din = D;
+        if (ups == 1 && (nskip != 1 || Din != D)) return NFT_EC_NOT_YET_IMPLEMENTED;
+        if (ups == 2 && (Din <= 2 || D != 2 * sub_count(Din, nskip))) return NFT_EC_INVALID_ARGUMENT;
         // largest product transform of the tree and chirp length must be within the split limits
         const size_t topN = (Dpad > 1) ? nft_product_len(Dpad / 2 * (size_t)deg0) : 2;
         if (topN > kMaxSplitTree) return NFT_EC_NOT_YET_IMPLEMENTED;
@@ -207,6 +228,13 @@ public:
         }
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
         ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
+        if (ups == 2) {
+            Lr = nft_nextpow2(2 * Din - 1);
+            if (Lr < 2 * (size_t)kRowChirp) Lr = 2 * (size_t)kRowChirp;
+            if (Lr > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
+            ok = ok && alloc(qpre, batch * D) && alloc(rsX, batch * Din) && alloc(rsX12, batch * 2 * Din)
+                 && alloc(rsQ12, batch * 2 * Din) && alloc(rsY, batch * 2 * Lr) && alloc(rsV, Lr);
+        }
         CoeffProgramHost prog;
         const bool has_prog = akns_disc >= 11 && akns_disc <= 18;   // 2SPLIT5A .. 2SPLIT8B
         if (has_prog) {
@@ -233,6 +261,7 @@ public:
         be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
         be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
         be.free(prog_bfrac); be.free(prog_mw); be.free(prog_ptr); be.free(prog_fac);
+        be.free(qpre); be.free(rsX); be.free(rsX12); be.free(rsQ12); be.free(rsY); be.free(rsV);
     }
 
     void upload_twiddles()
@@ -252,6 +281,58 @@ public:
             lo[j] = cmake((double)cosl(a), (double)sinl(a));
         }
         be.h2d(twlo, lo.data(), lo.size() * sizeof(cplx));
+    }
+
+    // ---- front end: fnft__nse_discretization_preprocess_signal (:386-656) + level 0 ------------
+    // T: interval of the Din input samples.  Tsub: interval of the kept steps (fnft_nsev.c:381-384),
+    // to be handed to run_contspec.
+    int run_front(const void *d_q, const double T[2], int kappa, double Tsub[2])
+    {
+        const double eps_in = (T[1] - T[0]) / (double)(Din - 1);
+        if (ups == 1) {
+            Tsub[0] = T[0];
+            Tsub[1] = T[1];
+            return run_coeffs(d_q, nullptr, eps_in, kappa);
+        }
+        const size_t Dsub = D / 2;
+        Tsub[0] = T[0];
+        Tsub[1] = T[0] + (double)((Dsub - 1) * nskip) * eps_in;
+        const double eps_t = (Tsub[1] - Tsub[0]) / (double)(Dsub - 1);
+        // forward DFT of every signal (fnft__misc.c:366-370)
+        ChirpParams C;
+        std::memset(&C, 0, sizeof(C));
+        C.poly = (const cplx *)d_q;
+        C.deg = (long long)Din - 1;
+        C.batch = (int)batch;
+        C.npoly = 1;
+        C.M = (long long)Din;
+        C.Ybuf = rsY; C.Vbuf = rsV; C.Hbuf = rsX;
+        fill_chirp_geometry(C, Lr);
+        C.status = status;
+        C.cstype = -1;
+        C.dft_len = (long long)Din;
+        C.dft_sign = -1;
+        int rc = run_chirp(C);
+        if (rc != NFT_SUCCESS) return rc;
+        // phase ramps for the shifts -/+ sqrt(3)/6 of the kept step (:482-485, fnft__misc.c:383-393)
+        ResampleParams R;
+        R.X = rsX; R.X12 = rsX12; R.Q12 = rsQ12; R.qpre = qpre;
+        R.Din = (long long)Din; R.Dsub = (long long)Dsub; R.nskip = (long long)nskip;
+        R.batch = (int)batch;
+        const double scl = std::sqrt(3.0) / 6.0;
+        R.delta_over_span = scl * (double)nskip / (double)Din;
+        R.w0 = 0.25 + scl;
+        R.w1 = 0.25 - scl;
+        be.template run<KResamplePhase>((int)((batch * Din + 255) / 256), 1, R);
+        // inverse DFTs (:395-399), then the weighted pairs (:493-499)
+        C.poly = rsX12;
+        C.npoly = 2;
+        C.Hbuf = rsQ12;
+        C.dft_sign = +1;
+        rc = run_chirp(C);
+        if (rc != NFT_SUCCESS) return rc;
+        be.template run<KResampleCombine>((int)((batch * Dsub + 255) / 256), 1, R);
+        return run_coeffs(qpre, nullptr, eps_t, kappa);
     }
 
     // ---- level 0 from samples (fnft__akns_fscatter.c:116-917) --------------------------------
@@ -455,8 +536,11 @@ public:
 
     int run_contspec(void *d_contspec, const Contspec &cs)
     {
-        const double deg1 = (double)deg0;
-        const double eps_t = (cs.T[1] - cs.T[0]) / (double)(D - 1);
+        // step size and phase factors refer to D_given = D/upsampling (fnft_nsev.c:766-774);
+        // lambda -> z uses degree*upsampling (fnft__akns_discretization.c:204-219)
+        const double deg1 = (double)(deg0 * ups);
+        const size_t Dg = D / (size_t)ups;
+        const double eps_t = (cs.T[1] - cs.T[0]) / (double)(Dg - 1);
         const double eps_xi = (cs.XI[1] - cs.XI[0]) / (double)(M - 1);
         // lambda -> z, fnft__akns_discretization.c:204-219 called from fnft_nsev.c:822-827
         const double phiV = 2.0 * eps_xi * eps_t / deg1;
@@ -491,8 +575,8 @@ public:
         const double bc = 0.5;
         const bool shifted = (cs.nse_disc == 0 /*MODAL*/ || cs.nse_disc == 4 /*2SPLIT2A*/);
         C.pf_rho = -2.0 * (cs.T[1] + eps_t * bc) + (shifted ? eps_t / deg1 : 0.0);
-        C.pf_a = -eps_t * (double)D + (cs.T[1] + eps_t * bc) - (cs.T[0] - eps_t * bc);
-        C.pf_b = -eps_t * (double)D - (cs.T[1] + eps_t * bc) - (cs.T[0] - eps_t * bc)
+        C.pf_a = -eps_t * (double)Dg + (cs.T[1] + eps_t * bc) - (cs.T[0] - eps_t * bc);
+        C.pf_b = -eps_t * (double)Dg - (cs.T[1] + eps_t * bc) - (cs.T[0] - eps_t * bc)
                  + (shifted ? eps_t / deg1 : 0.0);
         C.cstype = cs.cstype;
         C.use_W = 1;  // W is the exponent actually taken out, whatever normalization_flag says

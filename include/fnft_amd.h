@@ -224,6 +224,12 @@ const char *fnft_amd_last_error(void);
  * discretization.  Allocates every workspace the call needs in HBM once. */
 FNFT_INT fnft_amd_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
                               fnft_nse_discretization_t discretization, int device);
+/* same, for the second (coarse) transform of Richardson extrapolation with 4SPLIT4A/B: the
+ * transform uses every nskip-th step of the D samples; the band-limited resampling of
+ * fnft__nse_discretization_preprocess_signal (src/private/fnft__nse_discretization.c:474-503)
+ * still sees all D samples.  nskip = 1 is fnft_amd_plan_create; other schemes accept only 1. */
+FNFT_INT fnft_amd_plan_create_sub(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
+                                  fnft_nse_discretization_t discretization, int device, FNFT_UINT nskip);
 void fnft_amd_plan_destroy(fnft_amd_plan_t *plan);
 /* Bytes of HBM the plan holds. */
 FNFT_UINT fnft_amd_plan_workspace_bytes(const fnft_amd_plan_t *plan);

@@ -118,19 +118,21 @@ int emu_nsev_contspec(size_t D, const std::complex<double> *q, const double *T, 
     EmuBackend be;
     const int akns = nft_nse_to_akns(nse_disc);
     if (akns < 0) return NFT_EC_INVALID_ARGUMENT;
-    NftPlan<EmuBackend> pl(be, D, M, 1, akns, nft_akns_degree(akns));
+    const int ups = nft_nse_upsampling(nse_disc);
+    NftPlan<EmuBackend> pl(be, (size_t)ups * D, M, 1, akns, nft_akns_degree(akns));
+    pl.set_front(D, 1, ups);
     int rc = pl.init();
     if (rc != NFT_SUCCESS) { pl.destroy(); return rc; }
-    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
     const size_t cs_len = M * (cstype == 0 ? 1 : (cstype == 1 ? 2 : 3));
     cplx *dq = (cplx *)be.alloc(D * sizeof(cplx));
     cplx *dcs = (cplx *)be.alloc(cs_len * sizeof(cplx));
     be.h2d(dq, q, D * sizeof(cplx));
-    rc = pl.run_coeffs(dq, nullptr, eps_t, kappa);
+    double Tsub[2];
+    rc = pl.run_front(dq, T, kappa, Tsub);
     if (rc == NFT_SUCCESS) rc = pl.run_tree();
     if (rc == NFT_SUCCESS) {
         NftPlan<EmuBackend>::Contspec cs;
-        cs.T[0] = T[0]; cs.T[1] = T[1]; cs.XI[0] = XI[0]; cs.XI[1] = XI[1];
+        cs.T[0] = Tsub[0]; cs.T[1] = Tsub[1]; cs.XI[0] = XI[0]; cs.XI[1] = XI[1];
         cs.nse_disc = nse_disc; cs.cstype = cstype; cs.normalization_flag = normalization_flag;
         rc = pl.run_contspec(dcs, cs);
     }

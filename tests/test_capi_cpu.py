@@ -92,8 +92,8 @@ def test_unknown_and_unsupported_options(capi):
     o.bound_state_localization = 1
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     o = capi.default_opts()
-    o.discretization = capi.NSE_DISC["4SPLIT4A"]
-    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    o.discretization = capi.NSE_DISC["CF4_2"]                                     # slow scheme, kappa = -1
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], kappa=-1, opts=o)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     o = capi.default_opts()
     o.richardson_extrapolation_flag = 1                                           # accepted; needs the GPU
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_OTHER

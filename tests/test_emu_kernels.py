@@ -135,7 +135,9 @@ def test_chirpz_golden(emu, fixtures):
                                              (300, 20, "2SPLIT5B", 1), (256, 16, "2SPLIT7A", 1),
                                              (257, 16, "2SPLIT8A", -1), (128, 16, "2SPLIT6B", 1),
                                              (100, 16, "2SPLIT6A", 1), (200, 16, "2SPLIT7B", -1),
-                                             (200, 16, "2SPLIT8B", 1), (96, 16, "2SPLIT5A", -1)])
+                                             (200, 16, "2SPLIT8B", 1), (96, 16, "2SPLIT5A", -1),
+                                             (512, 16, "4SPLIT4A", 1), (511, 16, "4SPLIT4B", 1),
+                                             (300, 16, "4SPLIT4A", -1)])
 def test_nsev_vs_oracle(emu, oracle, D, M, disc, kappa):
     """Whole pipeline in the emulator; D = 4097 with degree 2 reaches a split transform in the
     top level of the tree; D = 16384 (degree 1) and D = 8192 (degree 3, lengths that are not 2d)

@@ -17,6 +17,7 @@ EPS = np.finfo(np.float64).eps
 AKNS_SCHEMES = ["2SPLIT2_MODAL", "2SPLIT1A", "2SPLIT1B", "2SPLIT2A", "2SPLIT2B", "2SPLIT2S",
                 "2SPLIT3A", "2SPLIT3B", "2SPLIT3S", "2SPLIT4A", "2SPLIT4B", "2SPLIT5A", "2SPLIT5B",
                 "2SPLIT6A", "2SPLIT6B", "2SPLIT7A", "2SPLIT7B", "2SPLIT8A", "2SPLIT8B"]
+ALL_FAST = AKNS_SCHEMES + ["4SPLIT4A", "4SPLIT4B"]
 
 
 def tol_for(D):
@@ -133,6 +134,8 @@ def test_nse_fscatter_vs_oracle(capi, oracle, D, disc, kappa):
     (65536, 1000, "2SPLIT4B"),
     (1024, 1024, "2SPLIT5A"), (1025, 200, "2SPLIT5B"), (1024, 1024, "2SPLIT6A"), (4096, 4096, "2SPLIT6B"),
     (256, 256, "2SPLIT7A"), (512, 100, "2SPLIT7B"), (1024, 512, "2SPLIT8A"), (2048, 2048, "2SPLIT8B"),
+    (512, 512, "4SPLIT4A"), (513, 100, "4SPLIT4B"), (1000, 64, "4SPLIT4A"), (4096, 4096, "4SPLIT4B"),
+    (3, 8, "4SPLIT4B"), (16384, 1000, "4SPLIT4A"),
 ])
 def test_fnft_nsev_vs_oracle(capi, oracle, D, M, disc):
     T, XI = [-25.0, 25.0], [-1.4, 1.6]
@@ -185,72 +188,60 @@ def _analytic_cases():
         fx = json.load(f)
     out = []
     for b in fx["nsev_error_bounds"]:
-        if b["discretization"] in AKNS_SCHEMES and b["testcase"] == "SECH_FOCUSING" \
+        if b["discretization"] in ALL_FAST and b["testcase"] != "SECH_FOCUSING2" \
                 and np.isfinite(b["error_bounds"][0]):
-            out.append(pytest.param(b, id=b["discretization"]))
+            out.append(pytest.param(b, id=b["file"].replace("fnft_nsev_test_", "").replace(".c", "")))
     return out
+
+
+def _exact(fixtures, testcase):
+    if testcase == "SECH_FOCUSING":
+        fx = fixtures["nsev_sech_focusing"]
+        return fx, S.sech_focusing, S.l2c(fx["contspec"]), S.l2c(fx["ab"])
+    if testcase == "SECH_DEFOCUSING":
+        fx = fixtures["nsev_sech_defocusing"]
+        return fx, S.sech_defocusing, S.l2c(fx["contspec"]), None
+    fx = fixtures["nsev_truncated_soliton"]
+    return fx, S.truncated_soliton, S.truncated_soliton_contspec(fx["XI"], fx["M"]), None
 
 
 @pytest.mark.parametrize("b", _analytic_cases())
 def test_fnft_nsev_analytic_bounds(capi, fixtures, b):
-    """src/private/fnft__nsev_testcases.c:711-822 at D, D+1, D-1, 2D with the test's own bounds."""
-    fx = fixtures["nsev_sech_focusing"]
+    """src/private/fnft__nsev_testcases.c:711-822 driven as test/fnft_nsev/<file>.c drives it: every
+    harness call of the file -- D, D+1, D-1, the finer grid with rescaled bounds, the Richardson
+    stages -- is one entry of b["stages"] (tests/golden/extract_reference_fixtures.py)."""
+    fx, sig, exact_rho, exact_ab = _exact(fixtures, b["testcase"])
     M = fx["M"]
-    stages = [(b["D"], b["error_bounds"]), (b["D"] + 1, b["error_bounds"]), (b["D"] - 1, b["error_bounds"])]
-    if b.get("error_bounds_2D"):
-        stages.append((2 * b["D"], b["error_bounds_2D"]))
-    exact_rho, exact_ab = S.l2c(fx["contspec"]), S.l2c(fx["ab"])
-    for D, bounds in stages:
-        rc, cs = capi.fnft_nsev(S.sech_focusing(D), fx["T"], M, fx["XI"], kappa=1,
-                                discretization=b["discretization"], contspec_type="BOTH")
+    assert b["stages"]
+    for st in b["stages"]:
+        rc, cs = capi.fnft_nsev(sig(st["D"]), fx["T"], M, fx["XI"], kappa=fx["kappa"],
+                                discretization=b["discretization"], contspec_type="BOTH",
+                                richardson=bool(st["richardson"]))
         assert rc == 0, capi.last_error()
-        errs = [S.rel_err(cs[:M], exact_rho), S.rel_err(cs[M:2 * M], exact_ab[:M]),
-                S.rel_err(cs[2 * M:], exact_ab[M:])]
-        for e, bound in zip(errs, bounds):
-            assert e <= bound, (D, errs, bounds)
+        errs = [S.rel_err(cs[:M], exact_rho)]
+        if exact_ab is not None:
+            errs += [S.rel_err(cs[M:2 * M], exact_ab[:M]), S.rel_err(cs[2 * M:], exact_ab[M:])]
+        for e, bound in zip(errs, st["bounds"]):
+            if np.isfinite(bound):
+                assert e <= bound, (st, errs, b["file"])
 
 
-@pytest.mark.parametrize("testcase,kappa", [("SECH_FOCUSING", 1), ("SECH_DEFOCUSING", -1)])
-def test_fnft_nsev_richardson(capi, oracle, fixtures, testcase, kappa):
-    """richardson_extrapolation_flag = 1 (src/fnft_nsev.c:316-406) against the bounds of
-    test/fnft_nsev/fnft_nsev_test_sech_{focusing,defocusing}_2split4A.c (error_bounds_RE at D = 4096,
-    /16 at 2D) and against the oracle's restatement of the same combination."""
-    import json
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "tests", "golden", "reference_fixtures.json")) as f:
-        allb = json.load(f)["nsev_error_bounds"]
-    b = [x for x in allb if x["discretization"] == "2SPLIT4A" and x["testcase"] == testcase
-         and x.get("error_bounds_RE")][0]
-    fx = fixtures["nsev_sech_focusing" if kappa == 1 else "nsev_sech_defocusing"]
-    M = fx["M"]
-    sig = S.sech_focusing if kappa == 1 else S.sech_defocusing
-    exact_rho = S.l2c(fx["contspec"])
-    exact_ab = S.l2c(fx["ab"]) if kappa == 1 else None
-    for D, scl in ((b["D"], 1.0), (2 * b["D"], 1.0 / 16.0), (b["D"] + 1, None), (3001, None)):
-        q = sig(D)
-        rc, cs = capi.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, discretization="2SPLIT4A",
-                                contspec_type="BOTH", richardson=True)
-        assert rc == 0, capi.last_error()
-        rc2, ref = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, disc="2SPLIT4A", cstype="BOTH",
-                                    richardson=True)
-        assert rc2 == 0
-        for j in range(3):
-            assert S.rel_err(cs[j * M:(j + 1) * M], ref[j * M:(j + 1) * M]) < 1e-11, (D, j)
-        if scl is not None:
-            errs = [S.rel_err(cs[:M], exact_rho)]
-            if exact_ab is not None:
-                errs += [S.rel_err(cs[M:2 * M], exact_ab[:M]), S.rel_err(cs[2 * M:], exact_ab[M:])]
-            for e, bound in zip(errs, b["error_bounds_RE"]):
-                if np.isfinite(bound):
-                    assert e <= bound * scl, (D, errs, b["error_bounds_RE"])
-    # reflection-only layout goes through the same combination loop
-    q = sig(512)
-    rc, cs = capi.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, discretization="2SPLIT2A",
-                            contspec_type="REFLECTION_COEFFICIENT", richardson=True)
-    rc2, ref = oracle.fnft_nsev(q, fx["T"], M, fx["XI"], kappa=kappa, disc="2SPLIT2A", cstype="RHO",
+@pytest.mark.parametrize("disc,kappa,D", [("2SPLIT4A", 1, 4096), ("2SPLIT4A", -1, 4097), ("2SPLIT2A", 1, 3001),
+                                          ("4SPLIT4A", 1, 512), ("4SPLIT4B", -1, 800), ("4SPLIT4A", 1, 511)])
+def test_fnft_nsev_richardson_vs_oracle(capi, oracle, disc, kappa, D):
+    """richardson_extrapolation_flag = 1 (src/fnft_nsev.c:316-406) against the oracle's restatement
+    of the same combination (order 2 for 2SPLIT, 4 for 4SPLIT; coarse 4SPLIT pass resamples the
+    full signal)."""
+    T, XI, M = [-25.0, 25.0], [-1.4, 1.6], 64
+    q = S.sech_focusing(D, amp=3.2 if kappa == 1 else 1.1)
+    for cst, oc in (("BOTH", "BOTH"), ("REFLECTION_COEFFICIENT", "RHO")):
+        rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=kappa, discretization=disc, contspec_type=cst,
                                 richardson=True)
-    assert rc == 0 and rc2 == 0 and S.rel_err(cs, ref) < 1e-11
+        assert rc == 0, capi.last_error()
+        rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=kappa, disc=disc, cstype=oc, richardson=True)
+        assert rc2 == 0
+        for j in range(len(ref) // M):
+            assert S.rel_err(cs[j * M:(j + 1) * M], ref[j * M:(j + 1) * M]) < 1e-11, (cst, j)
 
 
 # ---- BASELINE.json full size: properties that do not need a CPU run of that size ---------------
