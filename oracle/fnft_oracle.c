@@ -964,3 +964,74 @@ static int orc_nsev_base(size_t D, const orc_cplx *q, const double *T, size_t M,
     /* subroutine failures surface as -abs(ec), fnft__errwarn.h:50-57,101 */
     return rc == ORC_SUCCESS ? rc : -abs(rc);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Korteweg-de Vries, vanishing boundaries (fnft_kdvv)                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* fnft__kdv_discretization.c:86-150: the 18 2SPLIT schemes share their names with the AKNS ones;
+ * both enumerations list them in the same order, AKNS has 2SPLIT2_MODAL in front */
+int orc_kdv_to_akns(int kdv_disc)
+{
+    return (kdv_disc >= ORC_KDV_2SPLIT1A && kdv_disc <= ORC_KDV_2SPLIT8B) ? kdv_disc + 1 : -1;
+}
+
+/* fnft__kdv_fscatter.c:36-43 */
+size_t orc_kdv_fscatter_numel(size_t D, int kdv_disc)
+{
+    const int a = orc_kdv_to_akns(kdv_disc);
+    return a < 0 ? 0 : orc_akns_fscatter_numel(D, a);
+}
+
+/* fnft__kdv_fscatter.c:45-83: r = -1 */
+int orc_kdv_fscatter(size_t D, const orc_cplx *u, double eps_t, orc_cplx *result, size_t *deg_ptr,
+                     int32_t *W_ptr, int kdv_disc)
+{
+    if (D == 0 || !u || !(eps_t > 0.0) || !result || !deg_ptr) return ORC_EC_INVALID_ARGUMENT;
+    const int a = orc_kdv_to_akns(kdv_disc);
+    if (a < 0) return ORC_EC_INVALID_ARGUMENT;
+    orc_cplx *r = malloc(D * sizeof(orc_cplx));
+    if (!r) return ORC_EC_NOMEM;
+    for (size_t i = 0; i < D; i++) r[i] = -1.0;
+    const int rc = orc_akns_fscatter(D, u, r, eps_t, result, deg_ptr, W_ptr, a);
+    free(r);
+    return rc;
+}
+
+/* fnft_kdvv.c:59-209: transfer matrix without normalisation, entries 12 and 22 on the grid
+ * -(XI0 + i*eps_xi), reflection coefficient e^{2 i xi (T1 + eps/2)} H12 / (2 i xi H22 - H12) */
+int orc_fnft_kdvv(size_t D, const orc_cplx *u, const double *T, size_t M, orc_cplx *contspec,
+                  const double *XI, int kdv_disc)
+{
+    if (D < 2 || !u || !T || !(T[0] < T[1]) || !contspec || !XI || !(XI[0] < XI[1]))
+        return ORC_EC_INVALID_ARGUMENT;
+    const size_t numel = orc_kdv_fscatter_numel(D, kdv_disc);
+    if (numel == 0) return ORC_EC_INVALID_ARGUMENT;
+    orc_cplx *tm = malloc(numel * sizeof(orc_cplx)), *H = malloc(2 * M * sizeof(orc_cplx));
+    if (!tm || !H) { free(tm); free(H); return ORC_EC_NOMEM; }
+    const double eps_t = (T[1] - T[0]) / (double)(D - 1);
+    const double eps_xi = (XI[1] - XI[0]) / (double)(M - 1);
+    size_t deg = 0;
+    int rc = orc_kdv_fscatter(D, u, eps_t, tm, &deg, NULL, kdv_disc);
+    if (rc == ORC_SUCCESS) {
+        const double deg1 = (double)orc_akns_degree(orc_kdv_to_akns(kdv_disc));
+        const double bc = 0.5; /* fnft__akns_discretization.c:72-109 */
+        const orc_cplx V = cexp(-2.0 * I * eps_xi * eps_t / deg1);
+        const orc_cplx A = cexp(2.0 * I * XI[0] * eps_t / deg1);
+        orc_cplx *H12 = H, *H22 = H + M;
+        rc = orc_poly_chirpz(deg, tm + (deg + 1), A, V, M, H12);
+        if (rc == ORC_SUCCESS) rc = orc_poly_chirpz(deg, tm + 3 * (deg + 1), A, V, M, H22);
+        if (rc == ORC_SUCCESS) {
+            for (size_t i = 0; i < M; i++) {
+                const double xi = -XI[0] - (double)i * eps_xi;
+                if (kdv_disc == ORC_KDV_2SPLIT2A) H12[i] /= cexp(I * xi * eps_t / deg1); /* :186-195 */
+                contspec[i] = cexp(2.0 * I * xi * (T[1] + bc * eps_t)) * H12[i];
+                contspec[i] /= 2.0 * I * xi * H22[i] - H12[i];
+            }
+        }
+    }
+    free(tm);
+    free(H);
+    return rc == ORC_SUCCESS ? rc : -abs(rc);
+}
+

@@ -124,4 +124,18 @@ int orc_fnft_nsev_ex(size_t D, const orc_cplx *q, const double *T, size_t M, orc
 /* wall-clock seconds spent in the last orc_fnft_nsev call: [0] fscatter, [1] contspec */
 void orc_last_timings(double out[2]);
 
+/* ---- fnft_kdvv (src/fnft_kdvv.c), include/fnft_kdv_discretization_t.h:96-122 ordinals ---- */
+enum {
+    ORC_KDV_2SPLIT1A = 0, ORC_KDV_2SPLIT1B, ORC_KDV_2SPLIT2A, ORC_KDV_2SPLIT2B, ORC_KDV_2SPLIT2S,
+    ORC_KDV_2SPLIT3A, ORC_KDV_2SPLIT3B, ORC_KDV_2SPLIT3S, ORC_KDV_2SPLIT4A, ORC_KDV_2SPLIT4B,
+    ORC_KDV_2SPLIT5A, ORC_KDV_2SPLIT5B, ORC_KDV_2SPLIT6A, ORC_KDV_2SPLIT6B, ORC_KDV_2SPLIT7A,
+    ORC_KDV_2SPLIT7B, ORC_KDV_2SPLIT8A, ORC_KDV_2SPLIT8B
+};
+int orc_kdv_to_akns(int kdv_disc);
+size_t orc_kdv_fscatter_numel(size_t D, int kdv_disc);
+int orc_kdv_fscatter(size_t D, const orc_cplx *u, double eps_t, orc_cplx *result, size_t *deg_ptr,
+                     int32_t *W_ptr, int kdv_disc);
+int orc_fnft_kdvv(size_t D, const orc_cplx *u, const double *T, size_t M, orc_cplx *contspec,
+                  const double *XI, int kdv_disc);
+
 #endif

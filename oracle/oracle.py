@@ -23,6 +23,10 @@ AKNS_DISC = {
     "2SPLIT5A": 11, "2SPLIT5B": 12, "2SPLIT6A": 13, "2SPLIT6B": 14, "2SPLIT7A": 15, "2SPLIT7B": 16,
     "2SPLIT8A": 17, "2SPLIT8B": 18, "4SPLIT4A": 20, "4SPLIT4B": 21,
 }
+KDV_DISC = {n: i for i, n in enumerate(
+    ["2SPLIT1A", "2SPLIT1B", "2SPLIT2A", "2SPLIT2B", "2SPLIT2S", "2SPLIT3A", "2SPLIT3B", "2SPLIT3S",
+     "2SPLIT4A", "2SPLIT4B", "2SPLIT5A", "2SPLIT5B", "2SPLIT6A", "2SPLIT6B", "2SPLIT7A", "2SPLIT7B",
+     "2SPLIT8A", "2SPLIT8B"])}
 CSTYPE = {"RHO": 0, "AB": 1, "BOTH": 2}
 
 
@@ -75,6 +79,12 @@ class Oracle:
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_fnft_nsev_ex.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_fnft_kdvv.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                    C.c_int]
+        L.orc_kdv_fscatter_numel.restype = C.c_size_t
+        L.orc_kdv_fscatter_numel.argtypes = [C.c_size_t, C.c_int]
+        L.orc_kdv_fscatter.argtypes = [C.c_size_t, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int]
         L.orc_last_timings.argtypes = [C.c_double * 2]
         L.orc_last_timings.restype = None
 
@@ -174,6 +184,28 @@ class Oracle:
         rc = self.lib.orc_fnft_nsev_ex(q.size, _ptr(q), _ptr(T), M, _ptr(out), _ptr(XI), kappa, n, c,
                                        1 if normalize else 0, 1 if richardson else 0)
         return rc, out
+
+    def fnft_kdvv(self, u, T, M, XI, disc="2SPLIT8B"):
+        """fnft_kdvv, reflection coefficient on M points.  Returns (rc, contspec)."""
+        u = _c128(u)
+        T = np.ascontiguousarray(T, np.float64)
+        XI = np.ascontiguousarray(XI, np.float64)
+        k = KDV_DISC[disc] if isinstance(disc, str) else int(disc)
+        out = np.zeros(M, np.complex128)
+        rc = self.lib.orc_fnft_kdvv(u.size, _ptr(u), _ptr(T), M, _ptr(out), _ptr(XI), k)
+        return rc, out
+
+    def kdv_fscatter(self, u, eps_t, disc, normalize=False):
+        u = _c128(u)
+        k = KDV_DISC[disc] if isinstance(disc, str) else int(disc)
+        numel = int(self.lib.orc_kdv_fscatter_numel(u.size, k))
+        res = np.zeros(max(numel, 1), np.complex128)
+        d = C.c_size_t(0)
+        W = C.c_int32(0)
+        rc = self.lib.orc_kdv_fscatter(u.size, _ptr(u), eps_t, _ptr(res), C.byref(d),
+                                       C.byref(W) if normalize else None, k)
+        dd = d.value
+        return rc, dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
 
     def last_timings(self):
         t = (C.c_double * 2)()

@@ -54,7 +54,7 @@ def array_init(src, name):
     return [ceval(x) for x in body.split(",") if x.strip()]
 
 
-def walk_stages(src):
+def walk_stages(src, arr_pat=r"error_bounds\w*", harness="nsev_testcases_test_fnft"):
     """Replays the body of one test/fnft_nsev/*.c file statement by statement -- D and DN updates,
     bound arrays and their rescaling loops, the Richardson flag -- and records every call of the
     harness nsev_testcases_test_fnft(tc, <D>, <bounds>, &opts) as
@@ -73,14 +73,14 @@ def walk_stages(src):
     body = src[src.index("main"):] if "main" in src else src
     # a "for (i=0; i<6; i++) X;" loop is one statement applying X to every entry
     tok = re.compile(
-        r"(?P<arr>REAL\s+(?P<an>error_bounds\w*)\s*\[\s*6\s*\]\s*=\s*\{(?P<av>.*?)\}\s*;)"
+        r"(?P<arr>REAL\s+(?P<an>" + arr_pat + r")\s*\[\s*6\s*\]\s*=\s*\{(?P<av>.*?)\}\s*;)"
         r"|(?P<decl>UINT\s+(?P<dn>D|DN)\s*=\s*(?P<dv>[^;]+);)"
-        r"|(?P<loop>for\s*\([^)]*\)\s*(?P<ln>error_bounds\w*)\s*\[\s*i\s*\]\s*(?P<lo>[*/])=\s*(?P<lv>[^;]+);)"
-        r"|(?P<one>(?P<on>error_bounds\w*)\s*\[\s*(?P<oi>\d+)\s*\]\s*(?P<oo>[*/])=\s*(?P<ov>[^;]+);)"
+        r"|(?P<loop>for\s*\([^)]*\)\s*(?P<ln>" + arr_pat + r")\s*\[\s*i\s*\]\s*(?P<lo>[*/])=\s*(?P<lv>[^;]+);)"
+        r"|(?P<one>(?P<on>" + arr_pat + r")\s*\[\s*(?P<oi>\d+)\s*\]\s*(?P<oo>[*/])=\s*(?P<ov>[^;]+);)"
         r"|(?P<dop>\bD\s*(?P<do>[*/+-])=\s*(?P<dval>[^;]+);)"
         r"|(?P<dset>\bD\s*=\s*(?P<dsv>[^;=]+);)"
         r"|(?P<rich>opts\.richardson_extrapolation_flag\s*=\s*(?P<rv>\d)\s*;)"
-        r"|(?P<call>nsev_testcases_test_fnft\s*\(\s*tc\s*,\s*(?P<cd>[^,]+),\s*(?P<ca>\w+)\s*,)",
+        r"|(?P<call>" + harness + r"\s*\(\s*tc\s*,\s*(?P<cd>[^,]+),\s*(?P<ca>\w+)\s*,)",
         flags=re.S)
     for m in tok.finditer(body):
         if m.group("arr"):
@@ -250,6 +250,51 @@ def main():
             "error_bounds_2D": vals2[:3] if vals2 else None,
         })
     out["nsev_error_bounds"] = bounds
+
+    # ---- KdV: analytic spectra and the per-scheme integration tests ------------------------
+    src = strip_comments(read("src/private/fnft__kdvv_testcases.c"))
+
+    def kcase(name, nxt):
+        i = src.index("case kdvv_testcases_" + name + ":", src.index("generate test case") if "generate test case" in src else 0)
+        # the first occurrence of the label is in the M switch; take the one that assigns values
+        cands = [m.start() for m in re.finditer(r"case kdvv_testcases_" + name + r"\s*:", src)]
+        i = cands[-1]
+        j = src.index(nxt, i) if nxt else len(src)
+        return src[i:j]
+
+    def kassign(block):
+        vals = {}
+        for m in re.finditer(r"\(\*contspec_ptr\)\[(\d+)\]\s*=\s*([^;]+);", block):
+            vals[int(m.group(1))] = ceval(m.group(2))
+        return [c2l(vals[i]) for i in range(len(vals))]
+
+    out["kdvv_sech"] = {
+        "signal": "u[i] = 3.2*sech(T0 + i*(T1-T0)/(D-1))**2",
+        "T": [-16.0, 15.0], "XI": [-71.0 / 20.0, 79.0 / 20.0], "M": 16,
+        "contspec": kassign(kcase("SECH", "case kdvv_testcases_RECT")),
+    }
+    out["kdvv_rect"] = {
+        "signal": "t=T0+i*eps: |t|==0.5 -> 0.5, |t|<0.5 -> 1, else 0",
+        "T": [-1.0, 2.0], "XI": [0.0, "15*pi/32"], "M": 16,
+        "contspec": kassign(kcase("RECT", "case kdvv_testcases_NEGATIVE_RECT")),
+    }
+    out["kdvv_negative_rect"] = {
+        "signal": "minus the rect signal",
+        "T": [-1.0, 2.0], "XI": [0.0, "15*pi/32"], "M": 16,
+        "contspec": kassign(kcase("NEGATIVE_RECT", "default:")),
+    }
+    kb = []
+    d = os.path.join(REF, "test/fnft_kdvv")
+    for fn in sorted(os.listdir(d)):
+        s2 = strip_comments(read("test/fnft_kdvv/" + fn))
+        mtc = re.search(r"kdvv_testcases_(NEGATIVE_RECT|RECT|SECH)\b", s2)
+        mdisc = re.search(r"opts\.discretization\s*=\s*kdv_discretization_(\w+)\s*;", s2)
+        if not mtc:
+            continue
+        kb.append({"file": fn, "testcase": mtc.group(1),
+                   "discretization": mdisc.group(1) if mdisc else "2SPLIT8B",
+                   "stages": walk_stages(s2, arr_pat=r"eb\w*|error_bounds\w*", harness="kdvv_testcases_test_fnft")})
+    out["kdvv_error_bounds"] = kb
 
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_fixtures.json")
     with open(dst, "w") as f:

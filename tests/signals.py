@@ -140,3 +140,28 @@ def contspec_tol(oracle, q, T, kappa, disc, floor):
     rc, deg, tm, W = oracle.nse_fscatter(q, eps_t, kappa, disc)
     cmax = float(np.max(np.abs(tm))) * 2.0 ** W
     return max(floor, 100 * 2.220446049250313e-16 * cmax * np.sqrt(deg))
+
+
+# ---- KdV test signals (src/private/fnft__kdvv_testcases.c:88-262) --------------------------------
+def kdvv_sech(D, T=(-16.0, 15.0)):
+    return (3.2 * sech(tgrid(T, D)) ** 2).astype(np.complex128)
+
+
+def kdvv_rect(D, T=(-1.0, 2.0), sign=1.0):
+    eps_t = (T[1] - T[0]) / (D - 1)
+    t = T[0] + np.arange(D) * eps_t
+    u = np.where(np.abs(t) == 0.5, 0.5, np.where(np.abs(t) < 0.5, 1.0, 0.0))
+    return (sign * u).astype(np.complex128)
+
+
+def kdvv_case(fixtures, testcase, D):
+    """(u, T, XI, M, exact contspec) of one reference KdV test case."""
+    key = {"SECH": "kdvv_sech", "RECT": "kdvv_rect", "NEGATIVE_RECT": "kdvv_negative_rect"}[testcase]
+    fx = fixtures[key]
+    T = fx["T"]
+    XI = [float(fx["XI"][0]), 15.0 * np.pi / 32.0 if isinstance(fx["XI"][1], str) else float(fx["XI"][1])]
+    if testcase == "SECH":
+        u = kdvv_sech(D, T)
+    else:
+        u = kdvv_rect(D, T, 1.0 if testcase == "RECT" else -1.0)
+    return u, T, XI, fx["M"], l2c(fx["contspec"])

@@ -175,3 +175,25 @@ def test_cstype_layouts(oracle):
     # rho = b/a up to the phase factors, independent of normalisation
     _, nonorm = oracle.fnft_nsev(q, T, M, XI, disc="2SPLIT4B", cstype="BOTH", normalize=False)
     assert S.rel_err(nonorm, both) < 1e-12
+
+
+# ---- fnft_kdvv: every harness call of test/fnft_kdvv/*.c ---------------------------------------
+def _kdvv_cases():
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_fixtures.json")) as f:
+        fx = json.load(f)
+    return [pytest.param(b, id=b["file"].replace("fnft_kdvv_test_", "").replace(".c", ""))
+            for b in fx["kdvv_error_bounds"]]
+
+
+@pytest.mark.parametrize("b", _kdvv_cases())
+def test_fnft_kdvv_analytic_bounds(oracle, fixtures, b):
+    """fnft__kdvv_testcases.c:294-367 driven as test/fnft_kdvv/<file>.c drives it."""
+    assert b["stages"]
+    for st in b["stages"]:
+        u, T, XI, M, exact = S.kdvv_case(fixtures, b["testcase"], st["D"])
+        rc, cs = oracle.fnft_kdvv(u, T, M, XI, b["discretization"])
+        assert rc == 0
+        assert S.rel_err(cs, exact) <= st["bounds"][0], (st, b["file"])
