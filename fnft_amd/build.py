@@ -13,8 +13,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfnft_amd.so")
 ARCH = "gfx950"
 
-SOURCES = ["hip_backend.hip", "fnft_nsev_host.c"]
-HEADERS = ["dev_compat.h", "fft_dev.h", "nft_kernels.h", "nft_dispatch.h", "nft_plan.h", "nft_api.h",
+SOURCES = ["hip_backend.hip", "fnft_nsev_host.c", "fnft_kdvv_host.c"]
+HEADERS = ["dev_compat.h", "fft_dev.h", "nft_kernels.h", "nft_dispatch.h", "nft_plan.h", "nft_api.h", "nft_schemes.h",
            os.path.join("..", "..", "include", "fnft_amd.h")]
 
 
@@ -40,6 +40,8 @@ def build(force=False, verbose=False):
          os.path.join(CSRC, "hip_backend.hip"), "-o", os.path.join(LIBDIR, "hip_backend.o")],
         [hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c",
          os.path.join(CSRC, "fnft_nsev_host.c"), "-o", os.path.join(LIBDIR, "fnft_nsev_host.o")],
+        [hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c",
+         os.path.join(CSRC, "fnft_kdvv_host.c"), "-o", os.path.join(LIBDIR, "fnft_kdvv_host.o")],
     ]
     for c in cmds:
         if verbose:

@@ -37,8 +37,17 @@ AKNS_DISC = {
     "2SPLIT5B": 12, "2SPLIT6A": 13, "2SPLIT6B": 14, "2SPLIT7A": 15, "2SPLIT7B": 16,
     "2SPLIT8A": 17, "2SPLIT8B": 18, "BO": 19, "4SPLIT4A": 20, "4SPLIT4B": 21,
 }
+KDV_DISC = {n: i for i, n in enumerate(
+    ["2SPLIT1A", "2SPLIT1B", "2SPLIT2A", "2SPLIT2B", "2SPLIT2S", "2SPLIT3A", "2SPLIT3B", "2SPLIT3S",
+     "2SPLIT4A", "2SPLIT4B", "2SPLIT5A", "2SPLIT5B", "2SPLIT6A", "2SPLIT6B", "2SPLIT7A", "2SPLIT7B",
+     "2SPLIT8A", "2SPLIT8B", "4SPLIT4A", "4SPLIT4B", "BO", "CF4_2", "CF4_3", "CF5_3", "CF6_4"])}
 CSTYPE = {"RHO": 0, "REFLECTION_COEFFICIENT": 0, "AB": 1, "BOTH": 2}
 CS_FACTOR = {0: 1, 1: 2, 2: 3}
+
+
+class KdvvOpts(C.Structure):
+    """fnft_kdvv_opts_t, include/fnft_kdvv.h:60-62."""
+    _fields_ = [("discretization", C.c_int)]
 
 
 class NsevOpts(C.Structure):
@@ -66,6 +75,8 @@ EXPORTED = [
     "fnft_amd_last_error", "fnft_amd_plan_create", "fnft_amd_plan_create_sub", "fnft_amd_plan_destroy",
     "fnft_amd_plan_workspace_bytes", "fnft_amd_nsev_contspec_device", "fnft_amd_plan_finish",
     "fnft_amd_plan_last_ms", "fnft_amd_plan_set_timing", "fnft_amd_plan_get_transfer_matrix",
+    "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
+    "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
 
 _lib = None
@@ -117,6 +128,18 @@ def load(path=None):
     L.fnft_amd_last_error.restype = C.c_char_p
     L.fnft_amd_plan_create.restype = i32
     L.fnft_amd_plan_create.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int]
+    L.fnft_kdvv_default_opts.restype = KdvvOpts
+    L.fnft_kdvv_default_opts.argtypes = []
+    L.fnft_kdvv.restype = i32
+    L.fnft_kdvv.argtypes = [sz, vp, vp, sz, vp, vp, vp, vp, vp, C.POINTER(KdvvOpts)]
+    L.fnft__kdv_fscatter_numel.restype = sz
+    L.fnft__kdv_fscatter_numel.argtypes = [sz, C.c_int]
+    L.fnft__kdv_fscatter.restype = i32
+    L.fnft__kdv_fscatter.argtypes = [sz, vp, dbl, vp, C.POINTER(sz), C.POINTER(i32), C.c_int]
+    L.fnft_amd_kdvv_plan_create.restype = i32
+    L.fnft_amd_kdvv_plan_create.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int]
+    L.fnft_amd_kdvv_contspec_device.restype = i32
+    L.fnft_amd_kdvv_contspec_device.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl), vp]
     L.fnft_amd_plan_create_sub.restype = i32
     L.fnft_amd_plan_create_sub.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int, sz]
     L.fnft_amd_plan_destroy.restype = None
@@ -158,6 +181,10 @@ def last_error():
 def silence_errors(lib=None):
     """fnft_errwarn_setprintf(NULL): the reference's way of disabling error text."""
     (lib or load()).fnft_errwarn_setprintf(None)
+
+
+def default_kdvv_opts():
+    return load().fnft_kdvv_default_opts()
 
 
 def default_opts():
@@ -243,6 +270,76 @@ def nse_fscatter(q, eps_t, kappa, discretization, normalize=True):
                               C.byref(W) if normalize else None, n)
     dd = d.value
     return int(rc), dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
+
+
+def fnft_kdvv(u, T, M, XI, discretization="2SPLIT8B", opts=None, want_contspec=True, K=None,
+              bound_states=None, normconsts=None):
+    """fnft_kdvv() through the C ABI with host buffers.  Returns (rc, contspec)."""
+    L = load()
+    u = _c128(u)
+    if opts is None:
+        opts = L.fnft_kdvv_default_opts()
+        opts.discretization = KDV_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    Tn = None if T is None else np.ascontiguousarray(T, np.float64)
+    XIn = None if XI is None else np.ascontiguousarray(XI, np.float64)
+    cs = np.zeros(max(M, 1), np.complex128) if want_contspec else None
+    Kc = C.c_size_t(K if K is not None else 0)
+    rc = L.fnft_kdvv(u.size, _ptr(u), None if Tn is None else _ptr(Tn), M, None if cs is None else _ptr(cs),
+                     None if XIn is None else _ptr(XIn), C.byref(Kc) if K is not None else None,
+                     None if bound_states is None else _ptr(bound_states),
+                     None if normconsts is None else _ptr(normconsts), C.byref(opts))
+    return int(rc), (cs[:M] if cs is not None else None)
+
+
+def kdv_fscatter(u, eps_t, discretization, normalize=True):
+    L = load()
+    u = _c128(u)
+    k = KDV_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    numel = int(L.fnft__kdv_fscatter_numel(u.size, k))
+    res = np.zeros(max(numel, 1), np.complex128)
+    d = C.c_size_t(0)
+    W = C.c_int32(0)
+    rc = L.fnft__kdv_fscatter(u.size, _ptr(u), eps_t, _ptr(res), C.byref(d),
+                              C.byref(W) if normalize else None, k)
+    dd = d.value
+    return int(rc), dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
+
+
+class KdvvPlan:
+    """Device-resident KdV transform (fnft_amd_kdvv_plan_create)."""
+
+    def __init__(self, D, M, batch=1, discretization="2SPLIT8B", device=0):
+        self.L = load()
+        self.D, self.M, self.batch = int(D), int(M), int(batch)
+        self.disc = KDV_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+        self.h = C.c_void_p()
+        rc = self.L.fnft_amd_kdvv_plan_create(C.byref(self.h), self.D, self.M, self.batch, self.disc, int(device))
+        if rc != FNFT_SUCCESS:
+            raise RuntimeError("fnft_amd_kdvv_plan_create rc=%d (%s)" % (rc, last_error()))
+
+    def close(self):
+        if self.h:
+            self.L.fnft_amd_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, on=True):
+        self.L.fnft_amd_plan_set_timing(self.h, 1 if on else 0)
+
+    def last_ms(self, which=2):
+        return float(self.L.fnft_amd_plan_last_ms(self.h, which))
+
+    def contspec_device(self, u_ptr, out_ptr, T, XI, stream=0):
+        return int(self.L.fnft_amd_kdvv_contspec_device(self.h, C.c_void_p(u_ptr), C.c_void_p(out_ptr),
+                                                        _d2(T), _d2(XI), C.c_void_p(stream)))
+
+    def finish(self, stream=0):
+        return int(self.L.fnft_amd_plan_finish(self.h, C.c_void_p(stream)))
 
 
 # --------------------------------------------------------------------------------------------

@@ -48,6 +48,11 @@ static FNFT_INT raise(FNFT_INT ec, const char *func, int line, const char *msg)
           FNFT_AMD_IFACE_MINOR, FNFT_AMD_IFACE_PATCH, FNFT_AMD_IFACE_SUFFIX);
     return ec;
 }
+/* shared with fnft_kdvv_host.c */
+FNFT_INT fnft_amd__raise(FNFT_INT ec, const char *func, int line, const char *msg)
+{
+    return raise(ec, func, line, msg);
+}
 #define E_INVALID_ARGUMENT(name) raise(FNFT_EC_INVALID_ARGUMENT, __func__, __LINE__, "Invalid argument " #name ".")
 #define E_NOT_YET_IMPLEMENTED(name, msg) \
     raise(FNFT_EC_NOT_YET_IMPLEMENTED, __func__, __LINE__, "Not yet implemented (" #name "). " msg)

@@ -110,6 +110,7 @@ struct fnft_amd_plan {
     Plan *pl = nullptr;
     int device = 0;
     int nse_disc = 0;
+    int kdv_disc = -1;   // >= 0: plan made by fnft_amd_kdvv_plan_create
     std::mutex mtx;
 };
 
@@ -234,6 +235,58 @@ FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, v
     return rc;
 }
 
+// ---- KdV ----------------------------------------------------------------------------------------
+FNFT_INT fnft_amd_kdvv_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
+                                   fnft_kdv_discretization_t discretization, int device)
+{
+    if (!plan || D < 2 || batch < 1 || M < 1) return FNFT_EC_INVALID_ARGUMENT;
+    const int kd = (int)discretization;
+    if (kd < 0) return FNFT_EC_INVALID_ARGUMENT;
+    if (kd > (int)fnft_kdv_discretization_2SPLIT8B) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    const int akns = kd + 1;   // same scheme names, fnft__kdv_discretization.c:86-150
+    if (!ensure_device(device)) return FNFT_EC_OTHER;
+    fnft_amd_plan *P = new (std::nothrow) fnft_amd_plan();
+    if (!P) return FNFT_EC_NOMEM;
+    P->device = device;
+    P->nse_disc = -1;
+    P->kdv_disc = kd;
+    P->pl = new (std::nothrow) Plan(P->be, D, M, batch, akns, nft_akns_degree(akns));
+    if (!P->pl) { delete P; return FNFT_EC_NOMEM; }
+    P->pl->kdv = true;
+    const int rc = P->pl->init();
+    if (rc != NFT_SUCCESS || P->be.failed) {
+        P->pl->destroy();
+        delete P->pl;
+        delete P;
+        return rc != NFT_SUCCESS ? rc : FNFT_EC_NOMEM;
+    }
+    (void)P->be.sync();
+    *plan = P;
+    return FNFT_SUCCESS;
+}
+
+FNFT_INT fnft_amd_kdvv_contspec_device(fnft_amd_plan_t *plan, const void *d_u, void *d_contspec,
+                                       const FNFT_REAL *T, const FNFT_REAL *XI, void *stream)
+{
+    if (!plan || plan->kdv_disc < 0 || !d_u || !d_contspec || !T || !(T[0] < T[1]) || !XI || !(XI[0] < XI[1]))
+        return FNFT_EC_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(plan->mtx);
+    if (!hip_ok(hipSetDevice(plan->device), "hipSetDevice")) return FNFT_EC_OTHER;
+    Plan &pl = *plan->pl;
+    plan->be.stream = (hipStream_t)stream;
+    plan->be.failed = false;
+    plan->be.mark(0);
+    double Tsub[2];
+    int rc = pl.run_front(d_u, T, 1, Tsub);
+    if (rc == NFT_SUCCESS) rc = pl.run_tree();
+    plan->be.mark(1);
+    if (rc == NFT_SUCCESS)
+        rc = pl.run_contspec_kdv(d_contspec, T, XI, plan->kdv_disc == (int)fnft_kdv_discretization_2SPLIT2A);
+    plan->be.mark(2);
+    if (plan->be.failed) return FNFT_EC_OTHER;
+    return rc;
+}
+
 FNFT_INT fnft_amd_plan_finish(fnft_amd_plan_t *plan, void *stream)
 {
     if (!plan) return FNFT_EC_INVALID_ARGUMENT;
@@ -331,6 +384,70 @@ FNFT_INT fnft__nse_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q, cons
     if (!ensure_device(0)) return FNFT_EC_OTHER;
     HipBackend be;
     return api_akns_fscatter(be, D, q, nullptr, eps_t, kappa, result, deg_ptr, W_ptr, a);
+}
+
+FNFT_UINT fnft__kdv_fscatter_numel(FNFT_UINT D, fnft_kdv_discretization_t discretization)
+{
+    const int kd = (int)discretization;
+    if (kd < 0 || kd > (int)fnft_kdv_discretization_2SPLIT8B) return 0;
+    return fnft__poly_fmult2x2_numel((FNFT_UINT)nft_akns_degree(kd + 1), D);
+}
+
+// src/private/fnft__kdv_fscatter.c:45-83
+FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, const FNFT_REAL eps_t,
+                            FNFT_COMPLEX *const result, FNFT_UINT *const deg_ptr, FNFT_INT *const W_ptr,
+                            fnft_kdv_discretization_t discretization)
+{
+    if (D == 0 || !u || !(eps_t > 0.0) || !result || !deg_ptr) return FNFT_EC_INVALID_ARGUMENT;
+    const int kd = (int)discretization;
+    if (kd < 0 || kd > (int)fnft_kdv_discretization_2SPLIT8B) return FNFT_EC_INVALID_ARGUMENT;
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    std::vector<std::complex<double>> r(D, std::complex<double>(-1.0, 0.0));
+    HipBackend be;
+    return api_akns_fscatter(be, D, (const std::complex<double> *)u, r.data(), eps_t, 1,
+                             (std::complex<double> *)result, deg_ptr, W_ptr, kd + 1);
+}
+
+// internal entry used by fnft_kdvv_host.c: host buffers in and out, plans cached per (D, M, scheme)
+FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const FNFT_REAL *T, FNFT_UINT M,
+                                      FNFT_COMPLEX *contspec, const FNFT_REAL *XI, int discretization)
+{
+    static std::mutex cache_mtx;
+    static std::map<std::tuple<size_t, size_t, int>, fnft_amd_plan *> cache;
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    fnft_amd_plan *P = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(cache_mtx);
+        auto key = std::make_tuple((size_t)D, (size_t)M, discretization);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            if (cache.size() >= 4) {
+                for (auto &kv : cache) fnft_amd_plan_destroy(kv.second);
+                cache.clear();
+            }
+            const FNFT_INT rc = fnft_amd_kdvv_plan_create(&P, D, M, 1, (fnft_kdv_discretization_t)discretization, 0);
+            if (rc != FNFT_SUCCESS) return rc;
+            cache[key] = P;
+        } else {
+            P = it->second;
+        }
+    }
+    cplx *du = nullptr, *dcs = nullptr;
+    if (!hip_ok(hipMalloc((void **)&du, D * sizeof(cplx)), "hipMalloc")) return FNFT_EC_NOMEM;
+    if (!hip_ok(hipMalloc((void **)&dcs, M * sizeof(cplx)), "hipMalloc")) {
+        (void)hipFree(du);
+        return FNFT_EC_NOMEM;
+    }
+    FNFT_INT rc = FNFT_SUCCESS;
+    if (!hip_ok(hipMemcpy(du, u, D * sizeof(cplx), hipMemcpyHostToDevice), "hipMemcpy(H2D)")) rc = FNFT_EC_OTHER;
+    if (rc == FNFT_SUCCESS) rc = fnft_amd_kdvv_contspec_device(P, du, dcs, T, XI, nullptr);
+    if (rc == FNFT_SUCCESS) rc = fnft_amd_plan_finish(P, nullptr);
+    if (rc == FNFT_SUCCESS)
+        if (!hip_ok(hipMemcpy(contspec, dcs, M * sizeof(cplx), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+            rc = FNFT_EC_OTHER;
+    (void)hipFree(du);
+    (void)hipFree(dcs);
+    return rc;
 }
 
 // ---- internal entry used by the C driver (fnft_nsev_host.c) ------------------------------------

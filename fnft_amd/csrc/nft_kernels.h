@@ -1541,6 +1541,22 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const C
             continue;
         }
         const double xi = C.xi0 + C.eps_xi * (double)m;  // fnft_nsev.c:784-785
+        if (C.cstype == 10) {
+            // KdV reflection coefficient, fnft_kdvv.c:186-203: slots hold H12 and H22, xi runs over
+            // -(XI0 + m*eps_xi); pf_a = -eps_t/deg undoes the 2SPLIT2A base change (else 0),
+            // pf_rho = 2*(T1 + eps_t/2).  No zero test: the reference divides unguarded.
+            double s, co;
+            cplx h12 = H[0][i];
+            if (C.pf_a != 0.0) {
+                fa_sincos(xi * C.pf_a, &s, &co);
+                h12 = h12 * cmake(co, s);
+            }
+            fa_sincos(xi * C.pf_rho, &s, &co);
+            const cplx h22 = H[1][i];
+            const cplx den = cmake(-2.0 * xi * h22.y - h12.x, 2.0 * xi * h22.x - h12.y);  // 2 i xi H22 - H12
+            C.contspec[(size_t)b * C.M + m] = c_div(h12 * cmake(co, s), den);
+            continue;
+        }
         const long long cs_len = C.M * (C.cstype == 0 ? 1 : (C.cstype == 1 ? 2 : 3));
         cplx *out = C.contspec + (size_t)b * cs_len;
         long long off = 0;

@@ -129,6 +129,9 @@ public:
     int *prog_ptr = nullptr;
     unsigned char *prog_fac = nullptr;
     int prog_nB = 0, prog_maxf = 0;
+    // KdV (fnft_kdvv): r = -1 for every sample (fnft__kdv_fscatter.c:74-75), general 2x2 tree
+    bool kdv = false;
+    cplx *rneg = nullptr;
     // 4SPLIT4A/B front end (set_front): Din input samples per signal, every nskip-th step kept,
     // ups preprocessed samples per kept step; D = ups * Dsub matrices enter the tree
     size_t Din = 0, nskip = 1;
@@ -228,6 +231,13 @@ public:
         }
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
         ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
+        if (kdv) {
+            ok = ok && alloc(rneg, batch * D);
+            if (ok) {
+                std::vector<cplx> h(batch * D, cmake(-1.0, 0.0));
+                be.h2d(rneg, h.data(), h.size() * sizeof(cplx));
+            }
+        }
         if (ups == 2) {
             Lr = nft_nextpow2(2 * Din - 1);
             if (Lr < 2 * (size_t)kRowChirp) Lr = 2 * (size_t)kRowChirp;
@@ -261,6 +271,7 @@ public:
         be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
         be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
         be.free(prog_bfrac); be.free(prog_mw); be.free(prog_ptr); be.free(prog_fac);
+        be.free(rneg);
         be.free(qpre); be.free(rsX); be.free(rsX12); be.free(rsQ12); be.free(rsY); be.free(rsV);
     }
 
@@ -292,7 +303,7 @@ public:
         if (ups == 1) {
             Tsub[0] = T[0];
             Tsub[1] = T[1];
-            return run_coeffs(d_q, nullptr, eps_in, kappa);
+            return run_coeffs(d_q, kdv ? rneg : nullptr, eps_in, kappa);
         }
         const size_t Dsub = D / 2;
         Tsub[0] = T[0];
@@ -580,6 +591,45 @@ public:
                  + (shifted ? eps_t / deg1 : 0.0);
         C.cstype = cs.cstype;
         C.use_W = 1;  // W is the exponent actually taken out, whatever normalization_flag says
+        return run_chirp(C);
+    }
+
+    // fnft_kdvv.c:126-209 (tf2contspec_negxi): entries 12 and 22 on the grid -(XI0 + m*eps_xi)
+    int run_contspec_kdv(void *d_contspec, const double T[2], const double XI[2], bool scheme_2A)
+    {
+        const double deg1 = (double)deg0;
+        const double eps_t = (T[1] - T[0]) / (double)(D - 1);
+        const double eps_xi = (XI[1] - XI[0]) / (double)(M - 1);
+        const double phiV = -2.0 * eps_xi * eps_t / deg1;   // :159
+        const double phiA = 2.0 * XI[0] * eps_t / deg1;     // :160
+        const std::complex<double> V(std::cos(phiV), std::sin(phiV));
+        const std::complex<double> A(std::cos(phiA), std::sin(phiA));
+        const std::complex<double> lV = nft_clog(V), lA = nft_clog(A);
+        ChirpParams C;
+        std::memset(&C, 0, sizeof(C));
+        C.body = body[cur]; C.tail = tail[cur]; C.scale = scale[cur];
+        C.plane = plane;
+        C.deg_tot = (long long)(Dpad * (size_t)deg0);
+        C.deg = (long long)res_deg;
+        C.batch = (int)batch;
+        C.npoly = 2;
+        C.ne = ne;
+        if (ne != 4) return NFT_EC_OTHER;   // explicit r: the general form
+        C.entry[0] = 1;   // H12, :165
+        C.entry[1] = 3;   // H22, :172
+        C.logA[0] = lA.real(); C.logA[1] = lA.imag();
+        C.logW[0] = lV.real(); C.logW[1] = lV.imag();
+        C.M = (long long)M;
+        C.Ybuf = chY; C.Vbuf = chV;
+        fill_chirp_geometry(C, Lc);
+        C.contspec = (cplx *)d_contspec;
+        C.W = wexp[cur];
+        C.status = status;
+        C.xi0 = -XI[0];
+        C.eps_xi = -eps_xi;
+        C.pf_rho = 2.0 * (T[1] + 0.5 * eps_t);          // :199, boundary coefficient 0.5
+        C.pf_a = scheme_2A ? -eps_t / deg1 : 0.0;       // :186-195
+        C.cstype = 10;
         return run_chirp(C);
     }
 

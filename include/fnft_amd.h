@@ -261,6 +261,69 @@ FNFT_INT fnft_amd_plan_get_transfer_matrix(fnft_amd_plan_t *plan, FNFT_UINT b,
                                            FNFT_COMPLEX *result_host, FNFT_UINT *deg,
                                            FNFT_INT *W);
 
+/* ======================================================================================== */
+/* 4. Korteweg-de Vries equation, vanishing boundaries (include/fnft_kdvv.h)                  */
+/* ======================================================================================== */
+
+/* include/fnft_kdv_discretization_t.h:96-122 (same ordinals) */
+typedef enum {
+    fnft_kdv_discretization_2SPLIT1A,
+    fnft_kdv_discretization_2SPLIT1B,
+    fnft_kdv_discretization_2SPLIT2A,
+    fnft_kdv_discretization_2SPLIT2B,
+    fnft_kdv_discretization_2SPLIT2S,
+    fnft_kdv_discretization_2SPLIT3A,
+    fnft_kdv_discretization_2SPLIT3B,
+    fnft_kdv_discretization_2SPLIT3S,
+    fnft_kdv_discretization_2SPLIT4A,
+    fnft_kdv_discretization_2SPLIT4B,
+    fnft_kdv_discretization_2SPLIT5A,
+    fnft_kdv_discretization_2SPLIT5B,
+    fnft_kdv_discretization_2SPLIT6A,
+    fnft_kdv_discretization_2SPLIT6B,
+    fnft_kdv_discretization_2SPLIT7A,
+    fnft_kdv_discretization_2SPLIT7B,
+    fnft_kdv_discretization_2SPLIT8A,
+    fnft_kdv_discretization_2SPLIT8B,
+    fnft_kdv_discretization_4SPLIT4A,
+    fnft_kdv_discretization_4SPLIT4B,
+    fnft_kdv_discretization_BO,
+    fnft_kdv_discretization_CF4_2,
+    fnft_kdv_discretization_CF4_3,
+    fnft_kdv_discretization_CF5_3,
+    fnft_kdv_discretization_CF6_4
+} fnft_kdv_discretization_t;
+
+/* include/fnft_kdvv.h:60-62 */
+typedef struct {
+    fnft_kdv_discretization_t discretization;
+} fnft_kdvv_opts_t;
+
+/* include/fnft_kdvv.h:73, src/fnft_kdvv.c:34-44: discretization = 2SPLIT8B */
+fnft_kdvv_opts_t fnft_kdvv_default_opts(void);
+
+/* Drop-in for include/fnft_kdvv.h:100-105 / src/fnft_kdvv.c:59-123: reflection coefficient of
+ * the KdV scattering problem on M points of XI.  Same argument checks in the same order; like the
+ * reference, K_ptr, bound_states and normconsts_or_residues must be NULL
+ * (FNFT_EC_NOT_YET_IMPLEMENTED otherwise).  The 18 2SPLIT schemes are covered. */
+FNFT_INT fnft_kdvv(const FNFT_UINT D, FNFT_COMPLEX *const u, FNFT_REAL const *const T, const FNFT_UINT M,
+                   FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI, FNFT_UINT *const K_ptr,
+                   FNFT_COMPLEX *const bound_states, FNFT_COMPLEX *const normconsts_or_residues,
+                   fnft_kdvv_opts_t *opts_ptr);
+
+/* private seam, include/private/fnft__kdv_fscatter.h:50,84-86 */
+FNFT_UINT fnft__kdv_fscatter_numel(FNFT_UINT D, fnft_kdv_discretization_t discretization);
+FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, const FNFT_REAL eps_t,
+                            FNFT_COMPLEX *const result, FNFT_UINT *const deg_ptr, FNFT_INT *const W_ptr,
+                            fnft_kdv_discretization_t discretization);
+
+/* device-resident KdV transform: plan as in section 3 (destroy / finish / last_ms / set_timing are
+ * shared); d_u: batch*D complex128, d_contspec: batch*M complex128 */
+FNFT_INT fnft_amd_kdvv_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
+                                   fnft_kdv_discretization_t discretization, int device);
+FNFT_INT fnft_amd_kdvv_contspec_device(fnft_amd_plan_t *plan, const void *d_u, void *d_contspec,
+                                       const FNFT_REAL *T, const FNFT_REAL *XI, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

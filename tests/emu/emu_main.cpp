@@ -144,4 +144,29 @@ int emu_nsev_contspec(size_t D, const std::complex<double> *q, const double *T, 
     return rc;
 }
 
+// fnft_kdvv reflection coefficient, host buffers (kdv_disc 0..17)
+int emu_kdvv_contspec(size_t D, const std::complex<double> *u, const double *T, size_t M,
+                      std::complex<double> *contspec, const double *XI, int kdv_disc)
+{
+    EmuBackend be;
+    const int akns = kdv_disc + 1;
+    NftPlan<EmuBackend> pl(be, D, M, 1, akns, nft_akns_degree(akns));
+    pl.kdv = true;
+    int rc = pl.init();
+    if (rc != NFT_SUCCESS) { pl.destroy(); return rc; }
+    cplx *du = (cplx *)be.alloc(D * sizeof(cplx));
+    cplx *dcs = (cplx *)be.alloc(M * sizeof(cplx));
+    be.h2d(du, u, D * sizeof(cplx));
+    double Tsub[2];
+    rc = pl.run_front(du, T, 1, Tsub);
+    if (rc == NFT_SUCCESS) rc = pl.run_tree();
+    if (rc == NFT_SUCCESS) rc = pl.run_contspec_kdv(dcs, T, XI, kdv_disc == 2);
+    if (rc == NFT_SUCCESS) rc = pl.read_status();
+    if (rc == NFT_SUCCESS) be.d2h(contspec, dcs, M * sizeof(cplx));
+    be.free(du);
+    be.free(dcs);
+    pl.destroy();
+    return rc;
+}
+
 }  // extern "C"

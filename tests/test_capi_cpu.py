@@ -159,3 +159,22 @@ def test_no_gpu_means_loud_failure(capi):
     assert capi.poly_fmult2x2(1, 2, np.ones((4, 4), np.complex128))[0] == capi.FNFT_EC_OTHER
     with pytest.raises(RuntimeError):
         capi.Plan(64, 16)
+
+
+def test_kdvv_defaults_and_validation(capi):
+    """src/fnft_kdvv.c:34-44 (default 2SPLIT8B) and :77-94 (checks and their order); the checks run
+    before anything touches the GPU."""
+    capi.silence_errors()
+    assert capi.default_kdvv_opts().discretization == capi.KDV_DISC["2SPLIT8B"]
+    u = np.ones(8, np.complex128)
+    assert capi.fnft_kdvv(u[:1], [0, 1], 4, [-1, 1])[0] == 2                       # D
+    assert capi.fnft_kdvv(u, [1, 0], 4, [-1, 1])[0] == 2                           # T
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], want_contspec=False)[0] == 2      # contspec == NULL
+    assert capi.fnft_kdvv(u, [0, 1], 4, [1, -1])[0] == 2                           # XI
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], K=3)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    bs = np.zeros(4, np.complex128)
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], bound_states=bs)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], normconsts=bs)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization="CF4_2")[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization=99)[0] == -2
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1])[0] == capi.FNFT_EC_OTHER          # no GPU here

@@ -350,3 +350,83 @@ def test_modal_step_size_error(capi):
     q = np.full(16, 40.0 + 0j)
     rc, _ = capi.fnft_nsev(q, [0.0, 1.0], 8, [-1.0, 1.0], kappa=-1, discretization="2SPLIT2_MODAL")
     assert rc == -5
+
+
+# ---- fnft_kdvv -----------------------------------------------------------------------------------------
+def _kdvv_cases():
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_fixtures.json")) as f:
+        fx = json.load(f)
+    return [pytest.param(b, id=b["file"].replace("fnft_kdvv_test_", "").replace(".c", ""))
+            for b in fx["kdvv_error_bounds"]]
+
+
+@pytest.mark.parametrize("b", _kdvv_cases())
+def test_fnft_kdvv_analytic_bounds(capi, oracle, fixtures, b):
+    """src/private/fnft__kdvv_testcases.c:294-367 driven as test/fnft_kdvv/<file>.c drives it (all 37
+    files, every harness call), and the same calls against the oracle."""
+    assert b["stages"]
+    for st in b["stages"]:
+        u, T, XI, M, exact = S.kdvv_case(fixtures, b["testcase"], st["D"])
+        rc, cs = capi.fnft_kdvv(u, T, M, XI, discretization=b["discretization"])
+        assert rc == 0, capi.last_error()
+        assert S.rel_err(cs, exact) <= st["bounds"][0], (st, b["file"])
+        rc2, ref = oracle.fnft_kdvv(u, T, M, XI, b["discretization"])
+        assert rc2 == 0
+        assert S.rel_err(cs, ref) < (1e-9 if b["discretization"][6] in "5678" else 1e-11), (st, b["file"])
+
+
+@pytest.mark.parametrize("D,M,disc", [(4096, 4096, "2SPLIT4B"), (4097, 1000, "2SPLIT2A"), (65536, 65536, "2SPLIT4B"),
+                                      (16384, 16384, "2SPLIT8B"), (3000, 100, "2SPLIT3S")])
+def test_fnft_kdvv_vs_oracle(capi, oracle, D, M, disc):
+    T, XI = [-16.0, 15.0], [-71.0 / 20.0, 79.0 / 20.0]
+    u = S.kdvv_sech(D, T)
+    rc, cs = capi.fnft_kdvv(u, T, M, XI, discretization=disc)
+    assert rc == 0, capi.last_error()
+    rc2, ref = oracle.fnft_kdvv(u, T, M, XI, disc)
+    assert rc2 == 0
+    assert S.rel_err(cs, ref) < (2e-11 if D <= 4097 else 2e-10)
+
+
+def test_kdv_fscatter_vs_oracle(capi, oracle):
+    T = (-16.0, 15.0)
+    for D, disc in ((512, "2SPLIT4B"), (300, "2SPLIT2A"), (64, "2SPLIT8B")):
+        u = S.kdvv_sech(D, T)
+        eps_t = (T[1] - T[0]) / (D - 1)
+        rc, deg, tm, W = capi.kdv_fscatter(u, eps_t, disc)
+        assert rc == 0, capi.last_error()
+        rc2, deg2, ref, W2 = oracle.kdv_fscatter(u, eps_t, disc, normalize=True)
+        assert rc2 == 0 and deg == deg2
+        assert _tm_err(tm, W, ref, W2) < 1e-12
+
+
+def test_kdvv_device_batch(capi, oracle):
+    import torch
+    D, M, B = 2048, 512, 5
+    T, XI = [-16.0, 15.0], [-3.0, 3.5]
+    # amplitudes away from N(N+1) = 2, 6 (reflectionless potentials: rho ~ 0 has no relative accuracy)
+    us = np.stack([(1.1 + 0.37 * k) * S.kdvv_sech(D, T) / 3.2 for k in range(B)])
+    plan = capi.KdvvPlan(D, M, batch=B, discretization="2SPLIT4B")
+    du = torch.from_numpy(us).cuda()
+    out = torch.zeros(B * M, dtype=torch.complex128, device="cuda")
+    rc = plan.contspec_device(du.data_ptr(), out.data_ptr(), T, XI)
+    assert rc == 0, capi.last_error()
+    assert plan.finish() == 0
+    res = out.cpu().numpy().reshape(B, M)
+    for k in range(B):
+        rc2, ref = oracle.fnft_kdvv(us[k], T, M, XI, "2SPLIT4B")
+        assert rc2 == 0 and S.rel_err(res[k], ref) < 1e-11, k
+    plan.close()
+
+
+def test_kdvv_argument_errors(capi):
+    capi.silence_errors()
+    u = np.ones(8, np.complex128)
+    assert capi.fnft_kdvv(u[:1], [0, 1], 4, [-1, 1])[0] == 2
+    assert capi.fnft_kdvv(u, [1, 0], 4, [-1, 1])[0] == 2
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], want_contspec=False)[0] == 2
+    assert capi.fnft_kdvv(u, [0, 1], 4, [1, -1])[0] == 2
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], K=3)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization="BO")[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
