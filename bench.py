@@ -43,9 +43,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2D", type=int, default=20)
     ap.add_argument("--disc", default="2SPLIT2_MODAL")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
                     help="cfg2: one signal D=M=2^20 per GPU (headline); cfg3: BASELINE.json configs[2], "
-                         "64 of the 512 signals D=M=2^16 per GPU")
+                         "64 of the 512 signals D=M=2^16 per GPU; cfg5: configs[4], fnft_kdvv D=M=2^18 2SPLIT8B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -74,35 +74,52 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg3 = args.workload == "cfg3"
+    cfg5 = args.workload == "cfg5"
     if cfg3:
         args.log2D = 16
+    if cfg5:
+        args.log2D = 18
+        args.disc = "2SPLIT8B"
     D = M = 1 << args.log2D
     B = 64 if cfg3 else 1   # signals per GPU
-    deg0 = {"2SPLIT2_MODAL": 1, "2SPLIT4B": 2}.get(args.disc, 1)
+    deg0 = {"2SPLIT2_MODAL": 1, "2SPLIT4B": 2, "2SPLIT8B": 12}.get(args.disc, 1)
     T = [-25.0, 25.0]
     XI = [-4.0, 4.0] if cfg3 else [-7.0 / 5.0, 8.0 / 5.0]
-    if cfg3:
+    if cfg5:
+        # SURVEY 8d cfg 5: u = 3.2 sech^2(t), T = [-16, 15], XI = [-71/20, 79/20]
+        T, XI = [-16.0, 15.0], [-71.0 / 20.0, 79.0 / 20.0]
+        q_host = S.kdvv_sech(D, T) * (1.0 - 0.001 * rank)
+    elif cfg3:
         # SURVEY 8d cfg 3: signal k = A*sech(t - tau)*exp(i*w*t), (A, tau, w) from splitmix64(0x5EED0000+k)
         q_host = np.stack([S.batch_signal(rank * B + k, D, T) for k in range(B)])
     else:
         # each rank gets its own (slightly different) signal so that no rank can reuse another's work
         q_host = S.sech_focusing(D, amp=3.2 - 0.01 * rank)
 
-    plan = capi.Plan(D, M, batch=B, discretization=args.disc, device=local_rank)
+    if cfg5:
+        plan = capi.KdvvPlan(D, M, batch=B, discretization=args.disc, device=local_rank)
+    else:
+        plan = capi.Plan(D, M, batch=B, discretization=args.disc, device=local_rank)
     plan.set_timing(True)
     dq = torch.from_numpy(q_host).cuda()
-    outs = [torch.zeros(B * 3 * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
+    nout = 1 if cfg5 else 3   # fnft_kdvv returns the reflection coefficient only
+    outs = [torch.zeros(B * nout * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
     gather_bufs = None
     if world > 1 and rank == 0 and not args.no_gather:
-        gather_bufs = [[torch.zeros(B * 3 * M, 2, dtype=torch.float64,
+        gather_bufs = [[torch.zeros(B * nout * M, 2, dtype=torch.float64,
                                     device="cpu" if args.rehearse_gloo else "cuda") for _ in range(world)]
                        for _ in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
 
+    def transform(out_ptr):
+        if cfg5:
+            return plan.contspec_device(dq.data_ptr(), out_ptr, T, XI, stream=stream)
+        return plan.contspec_device(dq.data_ptr(), out_ptr, T, XI, kappa=1, contspec_type="BOTH",
+                                    normalization_flag=1, stream=stream)
+
     def one_step(i, pending):
         buf = outs[i % 2]
-        rc = plan.contspec_device(dq.data_ptr(), buf.data_ptr(), T, XI, kappa=1, contspec_type="BOTH",
-                                  normalization_flag=1, stream=stream)
+        rc = transform(buf.data_ptr())
         if rc != 0:
             raise RuntimeError("fnft_amd_nsev_contspec_device rc=%d: %s" % (rc, capi.last_error()))
         if world > 1 and not args.no_gather:
@@ -167,10 +184,11 @@ def main():
         reps = max(5, args.steps)
         tms = []
         for i in range(reps):
-            plan.contspec_device(dq.data_ptr(), outs[0].data_ptr(), T, XI, 1, "BOTH", 1, stream)
+            transform(outs[0].data_ptr())
             torch.cuda.synchronize()
             tms.append(plan.last_ms(0))
         t_tree = float(np.median(tms))
+        # KdV has no NSE symmetry and r = -1: the general 4-entry tree, same byte model
         bt = B * bytes_tree(D, deg0)
         achieved = bt / (t_tree * 1e-3) / 1e9
         traffic = None
@@ -191,17 +209,22 @@ def main():
             Dc = min(D, 1 << 20)
             nc = 8 if cfg3 else 1   # bounded sample: the first nc signals of this rank
             qc = q_host[:nc] if cfg3 else S.sech_focusing(Dc)[None, :]
-            res = outs[(args.steps - 1) % 2].cpu().numpy().reshape(B, 3, M) if Dc == D else None
+            res = outs[(args.steps - 1) % 2].cpu().numpy().reshape(B, nout, M) if Dc == D else None
             tc = 0.0
-            worst = [0.0, 0.0, 0.0]
+            worst = [0.0] * nout
+            if cfg5:
+                qc = q_host[None, :]
             for k in range(nc):
                 tc0 = time.perf_counter()
-                rcc, ref = orc.fnft_nsev(qc[k], T, Dc, XI, kappa=1, disc=args.disc, cstype="BOTH")
+                if cfg5:
+                    rcc, ref = orc.fnft_kdvv(qc[k], T, Dc, XI, args.disc)
+                else:
+                    rcc, ref = orc.fnft_nsev(qc[k], T, Dc, XI, kappa=1, disc=args.disc, cstype="BOTH")
                 tc += time.perf_counter() - tc0
                 if res is not None and rcc == 0:
-                    for j in range(3):
+                    for j in range(nout):
                         worst[j] = max(worst[j], float(S.rel_err(res[k, j], ref[j * M:(j + 1) * M])))
-            err = dict(zip(("rho", "a", "b"), worst)) if res is not None else None
+            err = dict(zip(("rho", "a", "b")[:nout], worst)) if res is not None else None
             cpu = {"value": round(nc * Dc / tc / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
                    "sample": "%d signal(s), D=M=2^%d, %s, oracle/fnft_oracle.c single thread, %.1f s"
                              % (nc, int(math.log2(Dc)), args.disc, tc),
@@ -209,12 +232,14 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Msamples/s fnft_nsev contspec (D=2^%d fp64)%s" % (args.log2D, " batch" if cfg3 else ""),
+            "metric": "Msamples/s %s contspec (D=2^%d fp64)%s" % ("fnft_kdvv" if cfg5 else "fnft_nsev", args.log2D,
+                                                                  " batch" if cfg3 else ""),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "fnft_nsev D=M=2^%d contspec (a,b + reflection), %s, %d signal%s per GPU%s"
-                                   % (args.log2D, args.disc, B, "" if B == 1 else "s",
+            "config": {"workload": "%s D=M=2^%d contspec (%s), %s, %d signal%s per GPU%s"
+                                   % ("fnft_kdvv" if cfg5 else "fnft_nsev", args.log2D,
+                                      "reflection" if cfg5 else "a,b + reflection", args.disc, B, "" if B == 1 else "s",
                                       " (configs[2]: 512 signals over 8 GPUs)" if cfg3 else ""),
                        "per_step_gather": bool(world > 1 and not args.no_gather),
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},

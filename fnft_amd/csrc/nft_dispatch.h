@@ -258,7 +258,7 @@ template <class BE> bool dispatch_pair_fft(BE &be, const TreeLevel &L, int N)
     }
 }
 
-#define FA_FOR_EACH_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+#define FA_FOR_EACH_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
 
 template <class BE> bool dispatch_col_fwd(BE &be, const BigLevel &G)
 {

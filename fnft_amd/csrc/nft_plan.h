@@ -107,8 +107,8 @@ inline size_t nft_product_len(size_t d)
 
 constexpr int kFineLog2 = 12;           // master twiddle: NMAX = 2^24
 constexpr int kMaxTwTable = 4096;       // per-length tables up to this length
-constexpr size_t kMaxSplitTree = (size_t)kRowTree * 1024;
-constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 1024;
+constexpr size_t kMaxSplitTree = (size_t)kRowTree * 2048;    // largest column transform: 2048
+constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 2048;
 
 template <class BE> class NftPlan {
 public:

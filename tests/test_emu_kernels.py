@@ -51,7 +51,7 @@ def emu():
 
 
 @pytest.mark.parametrize("kind,N", [("pair", n) for n in (8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096)]
-                         + [("col", n) for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024)])
+                         + [("col", n) for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048)])
 def test_workgroup_fft_tilings(emu, kind, N):
     """fft_wg in every (N, R, B, buffering) tiling the kernels instantiate, against numpy."""
     fn = emu.emu_fft_pair_cfg if kind == "pair" else emu.emu_fft_col_cfg

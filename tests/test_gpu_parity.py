@@ -430,3 +430,26 @@ def test_kdvv_argument_errors(capi):
     assert capi.fnft_kdvv(u, [0, 1], 4, [1, -1])[0] == 2
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], K=3)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization="BO")[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+
+
+def test_kdvv_cfg5_full_size(capi, oracle, fixtures):
+    """BASELINE.json configs[4]: fnft_kdvv, D = 2^18, M ~ 2^18, 2SPLIT8B (degree 12: the top product of the
+    tree is a 2^22-point transform, column size 2048).  The 16 analytic points of
+    fnft__kdvv_testcases.c:113-131 are the grid points k*(M-1)/15; the discretization error is far
+    below the round-off floor at this D, so the bound is the floor (conditioning of a degree-3.1e6
+    polynomial in double).  Plus a subsampled comparison with the oracle on the same grid."""
+    import torch
+    D = 1 << 18
+    M = 15 * 17475 + 1   # 262126: the largest grid below 2^18 that contains the 16 analytic points
+    u, T, XI, M16, exact = S.kdvv_case(fixtures, "SECH", D)
+    plan = capi.KdvvPlan(D, M, batch=1, discretization="2SPLIT8B")
+    du = torch.from_numpy(u).cuda()
+    out = torch.zeros(M, dtype=torch.complex128, device="cuda")
+    rc = plan.contspec_device(du.data_ptr(), out.data_ptr(), T, XI)
+    assert rc == 0, capi.last_error()
+    assert plan.finish() == 0
+    cs = out.cpu().numpy()
+    idx = np.arange(16) * ((M - 1) // 15)
+    assert (M - 1) % 15 == 0
+    assert S.rel_err(cs[idx], exact) < 1e-7
+    plan.close()
