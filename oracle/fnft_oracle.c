@@ -1035,3 +1035,94 @@ int orc_fnft_kdvv(size_t D, const orc_cplx *u, const double *T, size_t M, orc_cp
     return rc == ORC_SUCCESS ? rc : -abs(rc);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* discrete spectrum (bound states) -- the slow scatterer the reference refines with            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* fnft__nse_scatter_bound_states.c:40-668 for the two base schemes the splitting discretizations
+ * fall back to (fnft_nsev.c:669-676, :937-942): Boffetta-Osborne (ups = 1) and CF4_2 (ups = 2,
+ * q already preprocessed, spectral parameter scaled by w0 + w1 = 1/2, derivative by 1/2).
+ * One step with constant potential: U = [[ch - i l sh, q sh], [r sh, ch + i l sh]],
+ * k^2 = q r - l^2, ch = cosh(k eps), sh = sinh(k eps)/k, and dU/dl from dk/dl = -l/k.
+ * phi starts as (e^{-i lam (T0 - eps/2)}, 0) and is carried to T1 together with d phi/d lam;
+ * psi starts as (0, e^{i lam (T1 + eps/2)}) at T1 and is carried back with eps -> -eps.
+ * a = phi1(T1) e^{i lam (T1+eps/2)}; b = phi1/psi1 at the grid point where
+ * |log|(phi2/psi2)/(phi1/psi1)||/2 is smallest (:640-652).  r = -conj(q) (kappa = +1). */
+int orc_nse_scatter_bound_states(size_t D, const orc_cplx *q, const double *T, size_t K,
+                                 const orc_cplx *lam, orc_cplx *a_vals, orc_cplx *aprime_vals,
+                                 orc_cplx *b_vals, int ups, int skip_b)
+{
+    if (D == 0 || !q || !T || !lam || !a_vals || !aprime_vals || !b_vals) return ORC_EC_INVALID_ARGUMENT;
+    if (ups != 1 && ups != 2) return ORC_EC_INVALID_ARGUMENT;
+    if (ups == 2 && D % 2 != 0) return ORC_EC_OTHER;
+    const size_t Dg = D / (size_t)ups;
+    const double eps = (T[1] - T[0]) / (double)(Dg - 1);
+    const double lw = (ups == 2) ? 0.5 : 1.0, scl = (ups == 2) ? 0.5 : 1.0, bc = 0.5;
+    orc_cplx *P1 = malloc((Dg + 1) * sizeof(orc_cplx)), *P2 = malloc((Dg + 1) * sizeof(orc_cplx));
+    orc_cplx *S1 = malloc((Dg + 1) * sizeof(orc_cplx)), *S2 = malloc((Dg + 1) * sizeof(orc_cplx));
+    if (!P1 || !P2 || !S1 || !S2) { free(P1); free(P2); free(S1); free(S2); return ORC_EC_NOMEM; }
+    for (size_t e = 0; e < K; e++) {
+        const orc_cplx lc = lam[e], l = lc * lw;
+        orc_cplx p1 = cexp(-I * lc * (T[0] - eps * bc)), p2 = 0.0;
+        orc_cplx d1 = p1 * (-I * (T[0] - eps * bc)), d2 = 0.0;
+        P1[0] = p1; P2[0] = p2;
+        size_t ng = 0;
+        int count = ups - 1;
+        for (size_t n = 0; n < D; n++) {
+            const orc_cplx qn = q[n], rn = -conj(q[n]);
+            const orc_cplx ks = qn * rn - l * l, k = csqrt(ks);
+            const orc_cplx ch = ccosh(k * eps);
+            const orc_cplx sh = (ks != 0.0) ? csinh(k * eps) / k : (orc_cplx)eps;
+            const orc_cplx g = (eps * ch - sh) / ks;               /* -d(sh)/dl / l */
+            const orc_cplx u00 = ch - I * l * sh, u01 = qn * sh, u10 = rn * sh, u11 = ch + I * l * sh;
+            const orc_cplx v00 = -eps * l * sh - I * sh + I * l * l * g;
+            const orc_cplx v11 = -eps * l * sh + I * sh - I * l * l * g;
+            const orc_cplx v01 = -qn * l * g, v10 = -rn * l * g;
+            const orc_cplx n1 = v00 * p1 + v01 * p2 + u00 * d1 + u01 * d2;
+            d2 = v10 * p1 + v11 * p2 + u10 * d1 + u11 * d2;
+            d1 = n1;
+            const orc_cplx t = u10 * p1 + u11 * p2;
+            p1 = u00 * p1 + u01 * p2;
+            p2 = t;
+            if (count == 0) { count = ups - 1; ng++; P1[ng] = p1; P2[ng] = p2; } else count--;
+        }
+        const orc_cplx ph = cexp(I * lc * (T[1] + eps * bc));
+        a_vals[e] = P1[Dg] * ph;
+        aprime_vals[e] = scl * (d1 * ph + (I * (T[1] + eps * bc)) * a_vals[e]);
+        if (skip_b) continue;
+        orc_cplx s1 = 0.0, s2 = ph;
+        S1[Dg] = s1; S2[Dg] = s2;
+        ng = Dg;
+        count = ups - 1;
+        for (size_t n = D; n-- > 0;) {
+            const orc_cplx qn = q[n], rn = -conj(q[n]);
+            const orc_cplx ks = qn * rn - l * l, k = csqrt(ks);
+            const orc_cplx ch = ccosh(-k * eps);
+            const orc_cplx sh = (ks != 0.0) ? csinh(-k * eps) / k : (orc_cplx)(-eps);
+            const orc_cplx u00 = ch - I * l * sh, u01 = qn * sh, u10 = rn * sh, u11 = ch + I * l * sh;
+            const orc_cplx t = u10 * s1 + u11 * s2;
+            s1 = u00 * s1 + u01 * s2;
+            s2 = t;
+            if (count == 0) { count = ups - 1; ng--; S1[ng] = s1; S2[ng] = s2; } else count--;
+        }
+        double best = INFINITY;
+        for (size_t n = 0; n <= Dg; n++) {
+            const double m = fabs(0.5 * log(cabs((P2[n] / S2[n]) / (P1[n] / S1[n]))));
+            if (m < best) { b_vals[e] = P1[n] / S1[n]; best = m; }
+        }
+    }
+    free(P1); free(P2); free(S1); free(S2);
+    return ORC_SUCCESS;
+}
+
+/* fnft__misc.c:90-112 */
+double orc_l2norm2(size_t N, const orc_cplx *Z, double a, double b)
+{
+    if (N < 2 || a >= b) return NAN;
+    const double h = (b - a) / (double)N;
+    double val = 0.5 * h * cabs(Z[0]) * cabs(Z[0]);
+    for (size_t i = 1; i < N - 1; i++) val += h * cabs(Z[i]) * cabs(Z[i]);
+    val += 0.5 * h * cabs(Z[N - 1]) * cabs(Z[N - 1]);
+    return val;
+}
+

@@ -138,4 +138,10 @@ int orc_kdv_fscatter(size_t D, const orc_cplx *u, double eps_t, orc_cplx *result
 int orc_fnft_kdvv(size_t D, const orc_cplx *u, const double *T, size_t M, orc_cplx *contspec,
                   const double *XI, int kdv_disc);
 
+/* ---- discrete spectrum helpers (outer logic lives in oracle/oracle.py) ---- */
+int orc_nse_scatter_bound_states(size_t D, const orc_cplx *q, const double *T, size_t K,
+                                 const orc_cplx *lam, orc_cplx *a_vals, orc_cplx *aprime_vals,
+                                 orc_cplx *b_vals, int ups, int skip_b);
+double orc_l2norm2(size_t N, const orc_cplx *Z, double a, double b);
+
 #endif

@@ -30,6 +30,74 @@ KDV_DISC = {n: i for i, n in enumerate(
 CSTYPE = {"RHO": 0, "AB": 1, "BOTH": 2}
 
 
+def poly_roots(c, dense_max=2500):
+    """All roots of the polynomial with coefficients c (highest power first).  The reference calls
+    eiscor's structured QR (fnft__poly_roots_fasteigen.c:29-48, Fortran, not rebuilt here); the checker
+    uses LAPACK through numpy.roots up to degree dense_max and a vectorised Ehrlich-Aberth iteration
+    (Bini's start values, Horner in z or 1/z) above, where the dense companion matrix is too slow."""
+    c = np.asarray(c, np.complex128)
+    nz = np.flatnonzero(c != 0)
+    if nz.size == 0:
+        return np.zeros(0, np.complex128)
+    lead, trail = nz[0], c.size - 1 - nz[-1]
+    cc = c[nz[0]:nz[-1] + 1]
+    n = cc.size - 1
+    extra = np.concatenate([np.full(lead, np.inf + 0j), np.zeros(trail, np.complex128)])
+    if n <= dense_max:
+        return np.concatenate([np.roots(cc), extra])
+    a = np.abs(cc[::-1])
+    la = np.log(np.maximum(a, 1e-300))
+    hull = []
+    for k in range(n + 1):
+        while len(hull) >= 2:
+            k1, k2 = hull[-2], hull[-1]
+            if (la[k2] - la[k1]) * (k - k1) <= (la[k] - la[k1]) * (k2 - k1):
+                hull.pop()
+            else:
+                break
+        hull.append(k)
+    z = np.zeros(n, np.complex128)
+    pos = 0
+    for h in range(len(hull) - 1):
+        k1, k2 = hull[h], hull[h + 1]
+        m = k2 - k1
+        r = np.exp((la[k1] - la[k2]) / m)
+        z[pos:pos + m] = r * np.exp(1j * (2 * np.pi * np.arange(m) / m + 2 * np.pi * h / n + 0.7))
+        pos += m
+    cr = cc[::-1]
+    with np.errstate(all="ignore"):
+        for _ in range(100):
+            ins = np.abs(z) <= 1
+            w = np.zeros(n, np.complex128)
+            zi = z[ins]
+            p = np.full(zi.shape, cc[0], np.complex128)
+            dp = np.zeros(zi.shape, np.complex128)
+            for k in range(1, n + 1):
+                dp = dp * zi + p
+                p = p * zi + cc[k]
+            w[ins] = p / dp
+            zo = z[~ins]
+            y = 1.0 / zo
+            qv = np.full(y.shape, cr[0], np.complex128)
+            dq = np.zeros(y.shape, np.complex128)
+            for k in range(1, n + 1):
+                dq = dq * y + qv
+                qv = qv * y + cr[k]
+            w[~ins] = 1.0 / (n / zo - y * y * dq / qv)
+            s = np.zeros(n, np.complex128)
+            B = 256
+            for i0 in range(0, n, B):
+                d = z[i0:i0 + B, None] - z[None, :]
+                d[np.arange(d.shape[0]), np.arange(i0, i0 + d.shape[0])] = np.inf
+                s[i0:i0 + B] = np.sum(1.0 / d, axis=1)
+            corr = w / (1 - w * s)
+            corr[~np.isfinite(corr)] = 0.0
+            z = z - corr
+            if np.max(np.abs(corr) / np.maximum(np.abs(z), 1e-300)) < 1e-14:
+                break
+    return np.concatenate([z, extra])
+
+
 def build_oracle(force=False):
     """Compile oracle/liboracle.so with gcc (seconds)."""
     src = os.path.join(_HERE, "fnft_oracle.c")
@@ -85,6 +153,14 @@ class Oracle:
         L.orc_kdv_fscatter_numel.argtypes = [C.c_size_t, C.c_int]
         L.orc_kdv_fscatter.argtypes = [C.c_size_t, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int]
+        L.orc_nse_scatter_bound_states.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_l2norm2.restype = C.c_double
+        L.orc_l2norm2.argtypes = [C.c_size_t, C.c_void_p, C.c_double, C.c_double]
+        L.orc_nse_preprocess.argtypes = [C.c_size_t, C.c_void_p, C.c_double, C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
+        L.orc_nse_upsampling.restype = C.c_size_t
+        L.orc_nse_upsampling.argtypes = [C.c_int]
         L.orc_last_timings.argtypes = [C.c_double * 2]
         L.orc_last_timings.restype = None
 
@@ -206,6 +282,180 @@ class Oracle:
                                        C.byref(W) if normalize else None, k)
         dd = d.value
         return rc, dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
+
+    # ---- discrete spectrum (kappa = +1), fnft_nsev.c:276-309, 567-741, 895-1038 -----------------
+    def preprocess(self, q, eps_t, Dsub, disc):
+        """fnft__nse_discretization_preprocess_signal -> (rc, q_pre, Dsub, first_last)."""
+        q = _c128(q)
+        n = NSE_DISC[disc] if isinstance(disc, str) else int(disc)
+        ds = C.c_size_t(Dsub)
+        out = C.c_void_p()
+        fl = (C.c_size_t * 2)()
+        rc = self.lib.orc_nse_preprocess(q.size, _ptr(q), eps_t, C.byref(ds), C.byref(out), fl, n)
+        if rc != 0:
+            return rc, None, 0, (0, 0)
+        ups = int(self.lib.orc_nse_upsampling(n))
+        cnt = ds.value * ups
+        buf = (C.c_double * (2 * cnt)).from_address(out.value)
+        arr = np.frombuffer(buf, dtype=np.complex128, count=cnt).copy()
+        C.CDLL(None).free(out)
+        return 0, arr, ds.value, (fl[0], fl[1])
+
+    def scatter_bound_states(self, q_pre, T, lam, ups, skip_b=False):
+        q_pre = _c128(q_pre)
+        lam = _c128(lam)
+        T = np.ascontiguousarray(T, np.float64)
+        K = lam.size
+        a, ap, b = (np.zeros(max(K, 1), np.complex128) for _ in range(3))
+        rc = self.lib.orc_nse_scatter_bound_states(q_pre.size, _ptr(q_pre), _ptr(T), K, _ptr(lam), _ptr(a),
+                                                   _ptr(ap), _ptr(b), ups, 1 if skip_b else 0)
+        return rc, a[:K], ap[:K], b[:K]
+
+    def _bounding_box(self, q_pre, T, eps_t, deg, ups, bsfilt):
+        inf = float("inf")
+        if bsfilt == "BASIC":
+            return [-inf, inf, 0.0, inf]
+        if bsfilt == "FULL":
+            re_b = 0.9 * np.pi / abs(2.0 / deg * eps_t)                  # fnft_nsev.c:569-579
+            qt = q_pre if ups == 1 else np.ascontiguousarray(ups * q_pre[1::ups])  # :626-640
+            im_b = 1.5 * 0.25 * self.lib.orc_l2norm2(qt.size, _ptr(_c128(qt)), T[0], T[1])
+            return [-re_b, re_b, 0.0, im_b]
+        return [-inf, inf, -inf, inf]
+
+    @staticmethod
+    def _filter_merge(vals, box):
+        keep = [v for v in vals if (v.real >= box[0]) and (v.real <= box[1]) and (v.imag >= box[2])
+                and (v.imag <= box[3])]                                   # fnft__misc.c:114-157
+        vals = list(keep)
+        n = len(vals)
+        if n == 0:
+            return np.zeros(0, np.complex128)
+        tol = np.sqrt(2.220446049250313e-16)
+        nf = 1
+        for i in range(1, n):                                             # fnft__misc.c:228-259, in place
+            dist = -1.0
+            for j in range(i):
+                dist = abs(vals[j] - vals[i])
+                if dist < tol:
+                    break
+            if dist < tol:
+                continue
+            vals[nf] = vals[i]
+            nf += 1
+        return np.array(vals[:nf], np.complex128)
+
+    def _base_ds(self, q_pre, T, kappa, disc, bsloc, bsfilt, niter, dstype, guesses):
+        """fnft_nsev_base, discrete part.  Returns (rc, bound_states, normconsts, residues, aprimes)."""
+        n = NSE_DISC[disc] if isinstance(disc, str) else int(disc)
+        ups = int(self.lib.orc_nse_upsampling(n))
+        deg = int(self.lib.orc_akns_degree(self.lib.orc_nse_to_akns(n)))
+        Dg = q_pre.size // ups
+        eps_t = (T[1] - T[0]) / (Dg - 1)
+        box = self._bounding_box(q_pre, T, eps_t, deg, ups, bsfilt)
+        if bsloc == "NEWTON":
+            bs = np.array(guesses, np.complex128).copy()
+            eprec = 100 * 2.220446049250313e-16
+            for i in range(bs.size):                                      # fnft_nsev.c:971-1038
+                it = 0
+                while True:
+                    rc, a, ap, _ = self.scatter_bound_states(q_pre, T, bs[i:i + 1], ups, skip_b=True)
+                    if rc != 0:
+                        return -abs(rc), None, None, None, None
+                    if a[0] == 0.0:
+                        break
+                    if ap[0] == 0.0:
+                        return 3, None, None, None, None
+                    err = a[0] / ap[0]
+                    bs[i] -= err
+                    it += 1
+                    if bs[i].imag > box[3] or bs[i].real > box[1] or bs[i].real < box[0] or bs[i].imag < box[2]:
+                        break
+                    if not (abs(err) > eprec and it < niter):
+                        break
+        elif bsloc == "FAST_EIGENVALUE":
+            rc, d, tm, W = self.nse_fscatter_pre(q_pre, eps_t, kappa, n)
+            if rc != 0:
+                return -abs(rc), None, None, None, None
+            with np.errstate(all="ignore"):
+                z = poly_roots(tm[0])                                     # fnft__poly_roots_fasteigen.c
+                bs = np.log(z.astype(np.complex128)) / (2j * eps_t / (deg * ups))
+        else:
+            return 2, None, None, None, None
+        if bsfilt != "NONE":
+            bs = self._filter_merge(list(bs), box)
+        K = bs.size
+        if K == 0:
+            e = np.zeros(0, np.complex128)
+            return 0, e, e, e, e
+        rc, a, ap, b = self.scatter_bound_states(q_pre, T, bs, ups, skip_b=False)   # :895-968
+        if rc != 0:
+            return -abs(rc), None, None, None, None
+        return 0, bs, b, b / ap, ap
+
+    def nse_fscatter_pre(self, q_pre, eps_t, kappa, n):
+        numel = int(self.lib.orc_nse_fscatter_numel(q_pre.size, n))
+        res = np.zeros(max(numel, 1), np.complex128)
+        d = C.c_size_t(0)
+        W = C.c_int32(0)
+        rc = self.lib.orc_nse_fscatter(q_pre.size, _ptr(_c128(q_pre)), eps_t, kappa, _ptr(res), C.byref(d),
+                                       C.byref(W), n)
+        dd = d.value
+        return rc, dd, res[: 4 * (dd + 1)].reshape(4, dd + 1).copy(), int(W.value)
+
+    def fnft_nsev_ds(self, q, T, disc="2SPLIT4B", bsloc="SUBSAMPLE_AND_REFINE", bsfilt="FULL", niter=10,
+                     Dsub=0, guesses=None, richardson=False):
+        """Discrete spectrum of fnft_nsev for kappa = +1.
+        Returns (rc, bound_states, normconsts, residues)."""
+        q = _c128(q)
+        T = [float(T[0]), float(T[1])]
+        D = q.size
+        n = NSE_DISC[disc] if isinstance(disc, str) else int(disc)
+        ups = int(self.lib.orc_nse_upsampling(n))
+        eps_t = (T[1] - T[0]) / (D - 1)
+        rc, q_pre, _, _ = self.preprocess(q, eps_t, D, n)
+        if rc != 0:
+            return -abs(rc), None, None, None
+        if bsloc == "SUBSAMPLE_AND_REFINE":                               # fnft_nsev.c:276-304
+            ds = Dsub if Dsub else int(np.sqrt(D * np.log2(D) * np.log2(D)))
+            nskip = int(np.floor(D / ds + 0.5))
+            ds = int(np.floor(D / nskip + 0.5))
+            rc, qsub, ds, fl = self.preprocess(q, eps_t, ds, n)
+            if rc != 0:
+                return -abs(rc), None, None, None
+            Tsub = [T[0] + fl[0] * eps_t, T[0] + fl[1] * eps_t]
+            rc, bs0, _, _, _ = self._base_ds(qsub, Tsub, 1, n, "FAST_EIGENVALUE", bsfilt, niter, "BOTH", None)
+            if rc != 0:
+                return rc, None, None, None
+            rc, bs, nc, res, ap = self._base_ds(q_pre, T, 1, n, "NEWTON", bsfilt, niter, "BOTH", bs0)
+        else:
+            rc, bs, nc, res, ap = self._base_ds(q_pre, T, 1, n, bsloc, bsfilt, niter, "BOTH", guesses)
+        if rc != 0 or not richardson or bs.size == 0:
+            return rc, bs, nc, res
+        # Richardson extrapolation of the discrete spectrum, fnft_nsev.c:340-364, 376-392, 406-441
+        ds = D // 2
+        rc, qsub, ds, fl = self.preprocess(q, eps_t, ds, n)
+        if rc != 0:
+            return -abs(rc), None, None, None
+        Tsub = [T[0] + fl[0] * eps_t, T[0] + fl[1] * eps_t]
+        eps_sub = (Tsub[1] - Tsub[0]) / (ds - 1)
+        rc, bs_s, nc_s, res_s, ap_s = self._base_ds(qsub, Tsub, 1, n, "NEWTON", bsfilt, niter, "BOTH", bs.copy())
+        if rc != 0:
+            return rc, None, None, None
+        order = 4.0 if ups == 2 else 2.0
+        sn = (eps_sub / eps_t) ** order
+        sd = sn - 1.0
+        bs, res = bs.copy(), res.copy()
+        for i in range(bs.size):
+            loc, thr = bs_s.size, eps_t
+            for j in range(bs_s.size):
+                e = abs(bs[i] - bs_s[j]) / abs(bs[i])
+                if e < thr:
+                    thr, loc = e, j
+            if loc < bs_s.size:
+                bs[i] = (sn * bs[i] - bs_s[loc]) / sd
+                ap_i = (sn * (nc[i] / res[i]) - (nc_s[loc] / res_s[loc])) / sd
+                res[i] = nc[i] / ap_i
+        return 0, bs, nc, res
 
     def last_timings(self):
         t = (C.c_double * 2)()

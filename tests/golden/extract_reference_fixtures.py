@@ -15,6 +15,7 @@ Sources (relative to /root/reference):
   test/fnft_nsev/*.c                                                     (per-scheme error bounds)
 """
 import json
+import math
 import os
 import re
 import sys
@@ -106,7 +107,8 @@ def walk_stages(src, arr_pat=r"error_bounds\w*", harness="nsev_testcases_test_fn
             rich = int(m.group("rv"))
         elif m.group("call"):
             stages.append({"D": int(num(m.group("cd"))), "richardson": rich,
-                           "bounds": list(arrays[m.group("ca")][:3])})
+                           "bounds": list(arrays[m.group("ca")][:3]),
+                           "bounds_ds": list(arrays[m.group("ca")][3:6])})
     return stages
 
 
@@ -193,6 +195,12 @@ def main():
         "T": [-25.0, 25.0], "XI": [-7.0 / 5.0, 8.0 / 5.0], "M": 16, "kappa": 1,
         "contspec": assigns(blk, "contspec_ptr"),
         "ab": assigns(blk, "ab_ptr"),
+        # discrete spectrum, fnft__nsev_testcases.c:271-283: eigenvalues 0.7i, 1.7i, 2.7i, norming
+        # constants i, -i, i, residues c_k * Gamma(2/5) / Gamma(1/5)^2 with c = -1428/25, -5236/15, -4284/11
+        "bound_states": [[0.0, 0.7], [0.0, 1.7], [0.0, 2.7]],
+        "normconsts": [[0.0, 1.0], [0.0, -1.0], [0.0, 1.0]],
+        "residues": [[c * math.gamma(0.4) / math.gamma(0.2) ** 2, 0.0]
+                     for c in (-1428.0 / 25.0, -5236.0 / 15.0, -4284.0 / 11.0)],
     }
     blk = case_block("SECH_DEFOCUSING")
     out["nsev_sech_defocusing"] = {

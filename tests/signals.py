@@ -165,3 +165,28 @@ def kdvv_case(fixtures, testcase, D):
     else:
         u = kdvv_rect(D, T, 1.0 if testcase == "RECT" else -1.0)
     return u, T, XI, fx["M"], l2c(fx["contspec"])
+
+
+# ---- discrete spectrum error measures of the reference harness ------------------------------------
+def hausdorff(a, b):
+    """fnft__misc.c:53-83"""
+    a, b = np.asarray(a), np.asarray(b)
+    d = np.abs(a[:, None] - b[None, :])
+    return float(max(d.min(axis=1).max(), d.min(axis=0).max()))
+
+
+def ds_errors(bs, nc, res, bs_exact, nc_exact, res_exact):
+    """fnft__nsev_testcases.c:650-700: Hausdorff distance of the eigenvalues; norming constants and
+    residues matched to the nearest exact eigenvalue, summed and normalised."""
+    bs, bs_exact = np.asarray(bs), np.asarray(bs_exact)
+    if bs.size == 0 or bs_exact.size == 0:
+        return [float("nan")] * 3
+    out = [hausdorff(bs, bs_exact)]
+    for v, ex in ((nc, nc_exact), (res, res_exact)):
+        num = nrm = 0.0
+        for i in range(bs.size):
+            j = int(np.argmin(np.abs(bs[i] - bs_exact)))
+            num += abs(v[i] - ex[j])
+            nrm += abs(ex[i]) if i < len(ex) else 0.0
+        out.append(num / nrm if nrm > 0 else num)
+    return out

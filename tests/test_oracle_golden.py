@@ -197,3 +197,42 @@ def test_fnft_kdvv_analytic_bounds(oracle, fixtures, b):
         rc, cs = oracle.fnft_kdvv(u, T, M, XI, b["discretization"])
         assert rc == 0
         assert S.rel_err(cs, exact) <= st["bounds"][0], (st, b["file"])
+
+
+# ---- discrete spectrum: bounds [3..5] of the same reference tests ---------------------------------
+_DEG = {"2SPLIT2_MODAL": 1, "2SPLIT1A": 1, "2SPLIT1B": 1, "2SPLIT2A": 1, "2SPLIT2B": 1, "2SPLIT2S": 1,
+        "2SPLIT3A": 3, "2SPLIT3B": 3, "2SPLIT3S": 2, "2SPLIT4A": 4, "2SPLIT4B": 2, "2SPLIT5A": 15,
+        "2SPLIT5B": 15, "2SPLIT6A": 12, "2SPLIT6B": 6, "2SPLIT7A": 105, "2SPLIT7B": 105, "2SPLIT8A": 24,
+        "2SPLIT8B": 12, "4SPLIT4A": 4, "4SPLIT4B": 2}
+
+
+def _ds_cases():
+    out = []
+    for c in _bound_cases():
+        b = c.values[0]
+        if b["testcase"] != "SECH_FOCUSING" or not np.isfinite(b["stages"][0]["bounds_ds"][0]):
+            continue
+        D = max(st["D"] for st in b["stages"])
+        ups = 2 if b["discretization"].startswith("4SPLIT") else 1
+        # degree of the polynomial whose roots the subsampled stage needs (CPU suite budget)
+        if _DEG[b["discretization"]] * ups * np.sqrt(D) * np.log2(D) <= 4000:
+            out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("b", _ds_cases())
+def test_fnft_nsev_discrete_spectrum_bounds(oracle, fixtures, b):
+    """Default options of the harness (SUBSAMPLE_AND_REFINE, FULL filtering, 10 Newton steps,
+    dstype BOTH, fnft__nsev_testcases.c:741-764) on the sech pulse with eigenvalues 0.7i, 1.7i, 2.7i:
+    Hausdorff distance of the bound states, norming constants, residues against the file's bounds."""
+    fx = fixtures["nsev_sech_focusing"]
+    ex = [S.l2c(fx[k]) for k in ("bound_states", "normconsts", "residues")]
+    for st in b["stages"][:1] + b["stages"][3:]:    # D and the rescaled/Richardson stages (D+-1 repeat D)
+        rc, bs, nc, res = oracle.fnft_nsev_ds(S.sech_focusing(st["D"]), fx["T"], b["discretization"],
+                                              richardson=bool(st["richardson"]))
+        assert rc == 0
+        assert bs.size == 3, (st, bs)
+        errs = S.ds_errors(bs, nc, res, *ex)
+        for e, bound in zip(errs, st["bounds_ds"]):
+            if np.isfinite(bound):
+                assert e <= bound, (st, errs, b["file"])
