@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libfnft_amd.so")
 ARCH = "gfx950"
 
 SOURCES = ["hip_backend.hip", "fnft_nsev_host.c", "fnft_kdvv_host.c"]
-HEADERS = ["dev_compat.h", "fft_dev.h", "nft_kernels.h", "nft_dispatch.h", "nft_plan.h", "nft_api.h", "nft_schemes.h",
+HEADERS = ["dev_compat.h", "fft_dev.h", "nft_kernels.h", "nft_dispatch.h", "nft_plan.h", "nft_api.h", "nft_schemes.h", "nft_discspec.h",
            os.path.join("..", "..", "include", "fnft_amd.h")]
 
 

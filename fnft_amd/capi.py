@@ -196,8 +196,10 @@ def default_opts():
 # --------------------------------------------------------------------------------------------
 def fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="REFLECTION_COEFFICIENT",
               normalization_flag=1, opts=None, want_contspec=True, bound_states=None, K=None,
-              richardson=False):
-    """fnft_nsev() through the C ABI with host (numpy) buffers.  Returns (rc, contspec)."""
+              richardson=False, normconsts=None):
+    """fnft_nsev() through the C ABI with host (numpy) buffers.  Returns (rc, contspec).
+    bound_states / normconsts: caller-allocated complex128 arrays (K = capacity of bound_states);
+    see fnft_nsev_ds() for the discrete spectrum with managed buffers."""
     L = load()
     q = _c128(q)
     if opts is None:
@@ -214,9 +216,52 @@ def fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="RE
     rc = L.fnft_nsev(q.size, _ptr(q), None if Tn is None else _ptr(Tn), M,
                      None if cs is None else _ptr(cs), None if XIn is None else _ptr(XIn),
                      C.byref(Kc) if K is not None else None,
-                     None if bound_states is None else _ptr(bound_states), None, int(kappa),
-                     C.byref(opts))
+                     None if bound_states is None else _ptr(bound_states),
+                     None if normconsts is None else _ptr(normconsts), int(kappa), C.byref(opts))
+    if K is not None:
+        fnft_nsev.last_K = int(Kc.value)
     return int(rc), (cs[: M * fac] if cs is not None else None)
+
+
+BSLOC = {"FAST_EIGENVALUE": 0, "NEWTON": 1, "SUBSAMPLE_AND_REFINE": 2}
+BSFILT = {"NONE": 0, "BASIC": 1, "FULL": 2}
+DSTYPE = {"NORMING_CONSTANTS": 0, "RESIDUES": 1, "BOTH": 2}
+
+
+def fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="SUBSAMPLE_AND_REFINE", bsfilt="FULL", niter=10,
+                 Dsub=0, dstype="BOTH", guesses=None, richardson=False, M=0, XI=None, K=None):
+    """Discrete spectrum (kappa = +1) through the drop-in fnft_nsev().
+    Returns (rc, bound_states, normconsts, residues[, contspec if M > 0])."""
+    L = load()
+    q = _c128(q)
+    opts = L.fnft_nsev_default_opts()
+    opts.discretization = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    opts.bound_state_localization = BSLOC[bsloc] if isinstance(bsloc, str) else int(bsloc)
+    opts.bound_state_filtering = BSFILT[bsfilt] if isinstance(bsfilt, str) else int(bsfilt)
+    opts.niter = int(niter)
+    opts.Dsub = int(Dsub)
+    opts.discspec_type = DSTYPE[dstype] if isinstance(dstype, str) else int(dstype)
+    opts.contspec_type = CSTYPE["BOTH"]
+    opts.richardson_extrapolation_flag = 1 if richardson else 0
+    cap = int(K) if K is not None else int(L.fnft_nsev_max_K(q.size, C.byref(opts)))
+    bs = np.zeros(max(cap, 1), np.complex128)
+    if guesses is not None:
+        g = _c128(guesses)
+        bs[: g.size] = g
+        cap = g.size
+    nc = np.zeros(2 * max(cap, 1), np.complex128)
+    cs = np.zeros(3 * M, np.complex128) if M > 0 else None
+    Tn = np.ascontiguousarray(T, np.float64)
+    XIn = None if XI is None else np.ascontiguousarray(XI, np.float64)
+    Kc = C.c_size_t(cap)
+    rc = L.fnft_nsev(q.size, _ptr(q), _ptr(Tn), M, None if cs is None else _ptr(cs),
+                     None if XIn is None else _ptr(XIn), C.byref(Kc), _ptr(bs), _ptr(nc), 1, C.byref(opts))
+    k = int(Kc.value)
+    d = int(opts.discspec_type)
+    ncs = nc[:k] if d in (0, 2) else None
+    res = nc[k:2 * k] if d == 2 else (nc[:k] if d == 1 else None)
+    out = (int(rc), bs[:k].copy(), None if ncs is None else ncs.copy(), None if res is None else res.copy())
+    return out + ((cs,) if M > 0 else ())
 
 
 def poly_fmult2x2(deg, n, p, normalize=True):

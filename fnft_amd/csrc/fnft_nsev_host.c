@@ -25,6 +25,11 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                                       FNFT_INT kappa, int discretization, int contspec_type,
                                       FNFT_INT normalization_flag, FNFT_UINT nskip);
 
+FNFT_INT fnft_amd__nsev_discspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const FNFT_REAL *T, int bsfilt,
+                                      int bsloc, FNFT_UINT niter, FNFT_UINT Dsub, int dstype, int discretization,
+                                      int richardson, FNFT_UINT *K_ptr, FNFT_COMPLEX *bound_states,
+                                      FNFT_COMPLEX *normconsts_or_residues, int *warn);
+
 /* ---- error / warning text, src/fnft_errwarn.c:28-60 ---------------------------------------- */
 static FNFT_INT default_printf(const char *format, ...)
 {
@@ -117,7 +122,6 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
                    fnft_nsev_opts_t *opts)
 {
     FNFT_INT ret_code = FNFT_SUCCESS;
-    (void)normconsts_or_residues;
 
     /* same checks, same order as src/fnft_nsev.c:163-180 */
     if (D < 2) return E_INVALID_ARGUMENT(D);
@@ -198,8 +202,17 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
         return E_NOT_YET_IMPLEMENTED(discretization,
                                      "GPU path covers the fast (polynomial) discretizations.");
     }
-    if (kappa == +1 && bound_states != NULL)
-        return E_NOT_YET_IMPLEMENTED(bound_states, "Pass bound_states = NULL for the continuous spectrum.");
+    if (kappa == +1 && bound_states != NULL) {
+        /* option values that nsev_compute_boundstates / _normconsts_or_residues reject,
+         * src/fnft_nsev.c:717-719, :957-958 (wrapped once by CHECK_RETCODE in fnft_nsev_base, once in fnft_nsev) */
+        const int loc = (int)opts->bound_state_localization, dst = (int)opts->discspec_type;
+        if (loc < 0 || loc > 2) return E_INVALID_ARGUMENT(opts->bound_state_localization);
+        if (normconsts_or_residues != NULL && (dst < 0 || dst > 2)) {
+            ret_code = E_INVALID_ARGUMENT(opts->discspec_type);
+            ret_code = E_SUBROUTINE(ret_code);
+            return E_SUBROUTINE(ret_code);
+        }
+    }
     if (contspec != NULL && M > 0) {
         const int cst = (int)opts->contspec_type;
         if (cst < 0 || cst > 2) { /* src/fnft_nsev.c:880-883, raised inside nsev_compute_contspec */
@@ -270,7 +283,28 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
             return E_SUBROUTINE(ret_code);
         }
     }
-    /* src/fnft_nsev.c:558-560: no discrete spectrum was computed */
-    if (K_ptr != NULL) *K_ptr = 0;
+    /* discrete spectrum, src/fnft_nsev.c:276-309 (+ :406-441 with Richardson), :545-560 */
+    if (kappa == +1 && bound_states != NULL) {
+        int warn = 0;
+        ret_code = fnft_amd__nsev_discspec_host(D, q, T, (int)opts->bound_state_filtering,
+                                                (int)opts->bound_state_localization, opts->niter, opts->Dsub,
+                                                (int)opts->discspec_type, (int)opts->discretization,
+                                                opts->richardson_extrapolation_flag == 1, K_ptr, bound_states,
+                                                normconsts_or_residues, &warn);
+        if (warn) {
+            fnft_printf_ptr_t p = fnft_errwarn_getprintf();
+            if (p != NULL)
+                p("FNFT Warning: %s\n in %s(%i)-%d.%d.%d%s\n",
+                  "Found more than *K_ptr bound states. Returning as many as possible.", __func__, __LINE__,
+                  FNFT_AMD_IFACE_MAJOR, FNFT_AMD_IFACE_MINOR, FNFT_AMD_IFACE_PATCH, FNFT_AMD_IFACE_SUFFIX);
+        }
+        if (ret_code != FNFT_SUCCESS) {
+            if (ret_code == FNFT_EC_OTHER || ret_code == FNFT_EC_NOMEM)
+                return raise(ret_code, __func__, __LINE__, "GPU runtime failure (see fnft_amd_last_error()).");
+            return E_SUBROUTINE(ret_code);
+        }
+    } else if (K_ptr != NULL) {
+        *K_ptr = 0; /* src/fnft_nsev.c:558-560 */
+    }
     return FNFT_SUCCESS;
 }

@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "nft_api.h"
+#include "nft_discspec.h"
 #include "../../include/fnft_amd.h"
 
 static thread_local std::string g_last_error;
@@ -447,6 +448,28 @@ FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const 
             rc = FNFT_EC_OTHER;
     (void)hipFree(du);
     (void)hipFree(dcs);
+    return rc;
+}
+
+// internal entry used by fnft_nsev_host.c: discrete spectrum (kappa = +1), host buffers.
+// *K_ptr: capacity of bound_states in, number of bound states out.  *warn: more were found than fit.
+FNFT_INT fnft_amd__nsev_discspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const FNFT_REAL *T, int bsfilt,
+                                      int bsloc, FNFT_UINT niter, FNFT_UINT Dsub, int dstype, int discretization,
+                                      int richardson, FNFT_UINT *K_ptr, FNFT_COMPLEX *bound_states,
+                                      FNFT_COMPLEX *normconsts_or_residues, int *warn)
+{
+    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    HipBackend be;
+    NftDiscSpec<HipBackend> ds(be);
+    NftDsOpts o;
+    o.bsfilt = bsfilt; o.bsloc = bsloc; o.niter = niter; o.Dsub = Dsub; o.dstype = dstype;
+    o.nse_disc = discretization; o.richardson = richardson;
+    size_t K = *K_ptr;
+    const int rc = ds.run(D, (const std::complex<double> *)q, T, o, &K, (std::complex<double> *)bound_states,
+                          (std::complex<double> *)normconsts_or_residues);
+    if (warn) *warn = ds.warn_more_than_K;
+    if (be.failed) return FNFT_EC_OTHER;
+    if (rc == NFT_SUCCESS) *K_ptr = K;
     return rc;
 }
 

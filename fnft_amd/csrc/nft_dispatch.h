@@ -36,6 +36,48 @@ struct KResampleCombine {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_resample_combine(p); }
 };
+template <bool BACKWARD> struct KBsChunk {
+    using Params = BsParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_bs_chunk<BACKWARD>(p); }
+};
+template <bool BACKWARD> struct KBsCombine {
+    using Params = BsParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_bs_combine<BACKWARD>(p); }
+};
+struct KBsPhi {
+    using Params = BsParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_bs_phi(p); }
+};
+struct KBsMetric {
+    using Params = BsParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_bs_metric(p); }
+};
+struct KBsPick {
+    using Params = BsParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_bs_pick(p); }
+};
+struct KAberthNewton {
+    using Params = AberthParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_aberth_newton(p); }
+};
+struct KAberthUpdate {
+    using Params = AberthParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 256 * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_aberth_update<256>(p); }
+};
 template <int DEG> struct LeafCfg {
     static constexpr int SPT = (DEG == 1) ? 8 : (DEG == 2 ? 4 : 2);
 };

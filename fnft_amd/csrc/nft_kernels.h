@@ -1625,3 +1625,306 @@ FA_DEV void body_resample_combine(const ResampleParams &P)
     out[0] = q1 * P.w0 + q2 * P.w1;
     out[1] = q1 * P.w1 + q2 * P.w0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Discrete spectrum.  The reference refines and characterises bound states with a
+// sequential O(K*D) scatterer (fnft__nse_scatter_bound_states.c:40-668; Boffetta-Osborne for the
+// 2SPLIT schemes, CF4_2 for 4SPLIT4A/B, fnft_nsev.c:669-676,937-942).  The step matrices are
+// independent, so here the D steps are cut into chunks: one lane per (chunk, eigenvalue) forms the
+// chunk's 2x2 matrix (and its lambda-derivative), one lane per eigenvalue strings the chunks
+// together, and the per-point quantities needed for b are recomputed chunk-parallel from the
+// chunk boundary vectors.
+//   U(l) = [[ch - i l sh, q sh], [r sh, ch + i l sh]],  k^2 = q r - l^2, ch = cosh(k e), sh = sinh(k e)/k
+//   V = dU/dl from dk/dl = -l/k;  r = -conj(q)  (kappa = +1 is the only case with bound states)
+// ---------------------------------------------------------------------------------------------
+struct BsParams {
+    const cplx *q;       // D preprocessed samples of one signal
+    long long D;
+    int ups;             // 1: BO, 2: CF4_2 (spectral parameter and derivative scaled by 1/2)
+    double T0, T1, eps;  // eps = (T1 - T0)/(D/ups - 1)
+    int K;
+    const cplx *lam;     // K eigenvalue candidates
+    int L;               // samples per chunk, multiple of ups
+    int nchunk;
+    cplx *cm;            // K*nchunk*8: forward {M[4], M'[4]}; backward uses the first 4
+    cplx *bnd;           // K*(nchunk+1)*2: phi at the chunk starts, [nchunk] = end of the grid
+    cplx *bndp;          // K*(nchunk+1)*2: psi at the same points
+    cplx *PHI;           // K*(D/ups+1)*2: phi at every grid point
+    cplx *best;          // K*nchunk*2: {metric, 0}, b of the best point of the chunk
+    cplx *a, *aprime, *b;
+};
+
+FA_DEV void c_cosh_sinh(cplx w, cplx &ch, cplx &sh)
+{
+    double s, c;
+    fa_sincos(w.y, &s, &c);
+    const double chr = cosh(w.x), shr = sinh(w.x);
+    ch = cmake(chr * c, shr * s);
+    sh = cmake(shr * c, chr * s);
+}
+
+struct BsStep { cplx u00, u01, u10, u11; };
+// step matrix for step size e (e < 0: inverse step); V (derivative) only when WITH_D
+template <bool WITH_D> FA_DEV void bs_step(cplx q, cplx l, double e, BsStep &U, BsStep &V)
+{
+    const cplx r = cmake(-q.x, q.y);
+    const cplx ks = q * r - l * l;
+    const cplx k = c_sqrt(ks);
+    cplx ch, shk;
+    c_cosh_sinh(k * e, ch, shk);
+    const bool nz = (ks.x != 0.0 || ks.y != 0.0);
+    const cplx sh = nz ? c_div(shk, k) : cmake(e, 0.0);
+    const cplx il = cmake(-l.y, l.x);   // i*l
+    const cplx ilsh = il * sh;
+    U.u00 = ch - ilsh;
+    U.u01 = q * sh;
+    U.u10 = r * sh;
+    U.u11 = ch + ilsh;
+    if (WITH_D) {
+        const cplx g = c_div(ch * e - sh, ks);           // -(d sh/dl)/l
+        const cplx ish = cmake(-sh.y, sh.x);
+        const cplx t = (l * sh) * e;                     // e l sh
+        const cplx ill_g = (il * l) * g;                 // i l^2 g
+        V.u00 = cmake(0.0, 0.0) - t - ish + ill_g;
+        V.u11 = cmake(0.0, 0.0) - t + ish - ill_g;
+        const cplx lg = l * g;
+        V.u01 = cmake(0.0, 0.0) - q * lg;
+        V.u10 = cmake(0.0, 0.0) - r * lg;
+    }
+}
+
+// chunk matrices.  grid.x = nchunk lanes / THREADS, grid.y = K.  BACKWARD: inverse steps, last sample first
+template <bool BACKWARD> FA_DEV void body_bs_chunk(const BsParams &P)
+{
+    const int c = FA_BID * FA_BDIM + FA_TID, e = FA_BID_Y;
+    if (c >= P.nchunk) return;
+    const cplx l = P.lam[e] * (P.ups == 2 ? 0.5 : 1.0);
+    const long long n0 = (long long)c * P.L;
+    const long long n1 = (n0 + P.L < P.D) ? n0 + P.L : P.D;
+    cplx m00 = cmake(1.0, 0.0), m01 = cmake(0.0, 0.0), m10 = m01, m11 = m00;
+    cplx d00 = m01, d01 = m01, d10 = m01, d11 = m01;
+    BsStep U, V;
+    if (!BACKWARD) {
+        for (long long n = n0; n < n1; n++) {
+            bs_step<true>(P.q[n], l, P.eps, U, V);
+            // M' <- V M + U M',  M <- U M
+            const cplx e00 = V.u00 * m00 + V.u01 * m10 + U.u00 * d00 + U.u01 * d10;
+            const cplx e01 = V.u00 * m01 + V.u01 * m11 + U.u00 * d01 + U.u01 * d11;
+            const cplx e10 = V.u10 * m00 + V.u11 * m10 + U.u10 * d00 + U.u11 * d10;
+            const cplx e11 = V.u10 * m01 + V.u11 * m11 + U.u10 * d01 + U.u11 * d11;
+            d00 = e00; d01 = e01; d10 = e10; d11 = e11;
+            const cplx f00 = U.u00 * m00 + U.u01 * m10, f01 = U.u00 * m01 + U.u01 * m11;
+            const cplx f10 = U.u10 * m00 + U.u11 * m10, f11 = U.u10 * m01 + U.u11 * m11;
+            m00 = f00; m01 = f01; m10 = f10; m11 = f11;
+        }
+    } else {
+        for (long long n = n1; n-- > n0;) {
+            bs_step<false>(P.q[n], l, -P.eps, U, V);
+            const cplx f00 = U.u00 * m00 + U.u01 * m10, f01 = U.u00 * m01 + U.u01 * m11;
+            const cplx f10 = U.u10 * m00 + U.u11 * m10, f11 = U.u10 * m01 + U.u11 * m11;
+            m00 = f00; m01 = f01; m10 = f10; m11 = f11;
+        }
+    }
+    cplx *o = P.cm + ((size_t)e * P.nchunk + c) * 8;
+    o[0] = m00; o[1] = m01; o[2] = m10; o[3] = m11;
+    if (!BACKWARD) { o[4] = d00; o[5] = d01; o[6] = d10; o[7] = d11; }
+}
+
+// one lane per eigenvalue: string the chunks together.  Forward: a, a' (:627-628) and phi at the
+// chunk starts; backward: psi at the chunk ends.
+template <bool BACKWARD> FA_DEV void body_bs_combine(const BsParams &P)
+{
+    const int e = FA_BID * FA_BDIM + FA_TID;
+    if (e >= P.K) return;
+    const cplx lc = P.lam[e];
+    const double bc = 0.5;
+    const cplx *cmv = P.cm + (size_t)e * P.nchunk * 8;
+    double s, c;
+    const double tb = P.T1 + P.eps * bc;            // e^{i lam tb}
+    fa_sincos(lc.x * tb, &s, &c);
+    const cplx ph = cmake(c, s) * exp(-lc.y * tb);
+    if (!BACKWARD) {
+        const double ta = P.T0 - P.eps * bc;        // e^{-i lam ta}
+        fa_sincos(-lc.x * ta, &s, &c);
+        cplx p1 = cmake(c, s) * exp(lc.y * ta), p2 = cmake(0.0, 0.0);
+        cplx d1 = p1 * cmake(0.0, -ta), d2 = cmake(0.0, 0.0);
+        cplx *bnd = P.bnd + (size_t)e * (P.nchunk + 1) * 2;
+        for (int k = 0; k < P.nchunk; k++) {
+            bnd[2 * k] = p1; bnd[2 * k + 1] = p2;
+            const cplx *m = cmv + (size_t)k * 8;
+            const cplx n1 = m[4] * p1 + m[5] * p2 + m[0] * d1 + m[1] * d2;
+            const cplx n2 = m[6] * p1 + m[7] * p2 + m[2] * d1 + m[3] * d2;
+            d1 = n1; d2 = n2;
+            const cplx t1 = m[0] * p1 + m[1] * p2, t2 = m[2] * p1 + m[3] * p2;
+            p1 = t1; p2 = t2;
+        }
+        bnd[2 * P.nchunk] = p1; bnd[2 * P.nchunk + 1] = p2;
+        const cplx av = p1 * ph;
+        P.a[e] = av;
+        P.aprime[e] = (d1 * ph + cmake(0.0, tb) * av) * (P.ups == 2 ? 0.5 : 1.0);
+    } else {
+        cplx s1 = cmake(0.0, 0.0), s2 = ph;
+        cplx *bnd = P.bndp + (size_t)e * (P.nchunk + 1) * 2;
+        for (int k = P.nchunk; k-- > 0;) {
+            bnd[2 * (k + 1)] = s1; bnd[2 * (k + 1) + 1] = s2;
+            const cplx *m = cmv + (size_t)k * 8;
+            const cplx t1 = m[0] * s1 + m[1] * s2, t2 = m[2] * s1 + m[3] * s2;
+            s1 = t1; s2 = t2;
+        }
+        bnd[0] = s1; bnd[1] = s2;
+    }
+}
+
+// phi at every grid point of the chunk (grid point g+1 follows sample ups*(g+1)-1)
+FA_DEV void body_bs_phi(const BsParams &P)
+{
+    const int c = FA_BID * FA_BDIM + FA_TID, e = FA_BID_Y;
+    if (c >= P.nchunk) return;
+    const cplx l = P.lam[e] * (P.ups == 2 ? 0.5 : 1.0);
+    const long long n0 = (long long)c * P.L;
+    const long long n1 = (n0 + P.L < P.D) ? n0 + P.L : P.D;
+    const long long Dg = P.D / P.ups;
+    const cplx *bnd = P.bnd + ((size_t)e * (P.nchunk + 1) + c) * 2;
+    cplx p1 = bnd[0], p2 = bnd[1];
+    cplx *PHI = P.PHI + (size_t)e * (Dg + 1) * 2;
+    if (c == 0) { PHI[0] = p1; PHI[1] = p2; }
+    BsStep U, V;
+    for (long long n = n0; n < n1; n++) {
+        bs_step<false>(P.q[n], l, P.eps, U, V);
+        const cplx t1 = U.u00 * p1 + U.u01 * p2, t2 = U.u10 * p1 + U.u11 * p2;
+        p1 = t1; p2 = t2;
+        if ((n + 1) % P.ups == 0) {
+            const long long g = (n + 1) / P.ups;
+            PHI[2 * g] = p1; PHI[2 * g + 1] = p2;
+        }
+    }
+}
+
+FA_DEV double bs_metric(cplx p1, cplx p2, cplx s1, cplx s2)
+{   // |0.5 log |(phi2/psi2)/(phi1/psi1)||, :644
+    const cplx r = c_div(c_div(p2, s2), c_div(p1, s1));
+    return fabs(0.5 * log(sqrt(cnorm2(r))));
+}
+
+// psi backwards through the chunk; the chunk owns its grid points except its first one (chunk 0
+// owns point 0 too); best point of the chunk by the metric, first one on ties in ascending order
+FA_DEV void body_bs_metric(const BsParams &P)
+{
+    const int c = FA_BID * FA_BDIM + FA_TID, e = FA_BID_Y;
+    if (c >= P.nchunk) return;
+    const cplx l = P.lam[e] * (P.ups == 2 ? 0.5 : 1.0);
+    const long long n0 = (long long)c * P.L;
+    const long long n1 = (n0 + P.L < P.D) ? n0 + P.L : P.D;
+    const long long Dg = P.D / P.ups;
+    const cplx *bnd = P.bndp + ((size_t)e * (P.nchunk + 1) + (c + 1)) * 2;
+    cplx s1 = bnd[0], s2 = bnd[1];
+    const cplx *PHI = P.PHI + (size_t)e * (Dg + 1) * 2;
+    double best = 1.0e308 * 10.0;   // +inf
+    cplx bval = cmake(0.0, 0.0);
+    {
+        const long long g = n1 / P.ups;
+        const double m = bs_metric(PHI[2 * g], PHI[2 * g + 1], s1, s2);
+        if (m <= best) { best = m; bval = c_div(PHI[2 * g], s1); }
+    }
+    BsStep U, V;
+    for (long long n = n1; n-- > n0;) {
+        bs_step<false>(P.q[n], l, -P.eps, U, V);
+        const cplx t1 = U.u00 * s1 + U.u01 * s2, t2 = U.u10 * s1 + U.u11 * s2;
+        s1 = t1; s2 = t2;
+        if (n % P.ups == 0) {
+            const long long g = n / P.ups;
+            if (n > n0 || c == 0) {
+                const double m = bs_metric(PHI[2 * g], PHI[2 * g + 1], s1, s2);
+                if (m <= best) { best = m; bval = c_div(PHI[2 * g], s1); }
+            }
+        }
+    }
+    cplx *o = P.best + ((size_t)e * P.nchunk + c) * 2;
+    o[0] = cmake(best, 0.0);
+    o[1] = bval;
+}
+
+FA_DEV void body_bs_pick(const BsParams &P)
+{
+    const int e = FA_BID * FA_BDIM + FA_TID;
+    if (e >= P.K) return;
+    const cplx *bv = P.best + (size_t)e * P.nchunk * 2;
+    double best = 1.0e308 * 10.0;
+    cplx b = cmake(0.0, 0.0);
+    for (int c = 0; c < P.nchunk; c++)
+        if (bv[2 * c].x < best) { best = bv[2 * c].x; b = bv[2 * c + 1]; }
+    P.b[e] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// All roots of the a-polynomial: Ehrlich-Aberth iteration in place of the reference's structured
+// QR (eiscor through fnft__poly_roots_fasteigen.c:29-48, Fortran).  Every root estimate is a lane:
+// Newton correction p/p' by Horner in z (|z| <= 1) or in 1/z, then the Aberth sum over all others.
+// ---------------------------------------------------------------------------------------------
+struct AberthParams {
+    const cplx *coef;    // n+1 coefficients, highest power first
+    long long n;
+    cplx *z;             // n estimates
+    cplx *w;             // n Newton corrections
+    unsigned long long *maxcorr;   // bits of max |corr|/|z| of the sweep
+};
+
+FA_DEV void body_aberth_newton(const AberthParams &P)
+{
+    const long long k = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (k >= P.n) return;
+    const cplx z = P.z[k];
+    const long long n = P.n;
+    cplx w;
+    if (cnorm2(z) <= 1.0) {
+        cplx p = P.coef[0], dp = cmake(0.0, 0.0);
+        for (long long j = 1; j <= n; j++) {
+            dp = dp * z + p;
+            p = p * z + P.coef[j];
+        }
+        w = c_div(p, dp);
+    } else {
+        const cplx y = c_div(cmake(1.0, 0.0), z);
+        cplx p = P.coef[n], dp = cmake(0.0, 0.0);
+        for (long long j = 1; j <= n; j++) {
+            dp = dp * y + p;
+            p = p * y + P.coef[n - j];
+        }
+        // p(z) = z^n q(y):  p'/p = n/z - y^2 q'(y)/q(y)
+        const cplx t = y * (double)n - (y * y) * c_div(dp, p);
+        w = c_div(cmake(1.0, 0.0), t);
+    }
+    if (!(w.x == w.x) || !(w.y == w.y) || fabs(w.x) > 1.0e300 || fabs(w.y) > 1.0e300) w = cmake(0.0, 0.0);
+    P.w[k] = w;
+}
+
+template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
+{
+    FA_LDS_DECL
+    cplx *tile = (cplx *)FA_LDS_PTR;
+    const long long k = (long long)FA_BID * FA_BDIM + FA_TID;
+    const bool act = k < P.n;
+    const cplx zk = act ? P.z[k] : cmake(0.0, 0.0);
+    cplx s = cmake(0.0, 0.0);
+    for (long long j0 = 0; j0 < P.n; j0 += TILE) {
+        FA_SYNC();
+        if (j0 + FA_TID < P.n) tile[FA_TID] = P.z[j0 + FA_TID];
+        FA_SYNC();
+        const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
+        if (act)
+            for (int j = 0; j < lim; j++)
+                if (j0 + j != k) s = s + c_div(cmake(1.0, 0.0), zk - tile[j]);
+    }
+    FA_SYNC();
+    double rel = 0.0;
+    if (act) {
+        const cplx w = P.w[k];
+        cplx corr = c_div(w, cmake(1.0, 0.0) - w * s);
+        if (!(corr.x == corr.x) || !(corr.y == corr.y)) corr = cmake(0.0, 0.0);
+        const cplx zn = zk - corr;
+        P.z[k] = zn;
+        const double az = sqrt(cnorm2(zn));
+        rel = sqrt(cnorm2(corr)) / (az > 1.0e-300 ? az : 1.0e-300);
+    }
+    fa_wave_atomic_max_f64bits(P.maxcorr, rel);
+}

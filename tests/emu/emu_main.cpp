@@ -5,6 +5,7 @@
 thread_local fa_emu_ctx *fa_emu = nullptr;
 
 #include "../../fnft_amd/csrc/nft_api.h"
+#include "../../fnft_amd/csrc/nft_discspec.h"
 
 // ---- stand-alone checks of fft_wg in every tiling the kernels use -----------------------------
 struct FftTestParams {
@@ -167,6 +168,19 @@ int emu_kdvv_contspec(size_t D, const std::complex<double> *u, const double *T, 
     be.free(dcs);
     pl.destroy();
     return rc;
+}
+
+// discrete spectrum of fnft_nsev, host buffers (capacity *K_ptr in, count out)
+int emu_nsev_discspec(size_t D, const std::complex<double> *q, const double *T, int bsfilt, int bsloc,
+                      size_t niter, size_t Dsub, int dstype, int nse_disc, int richardson, size_t *K_ptr,
+                      std::complex<double> *bound_states, std::complex<double> *nc)
+{
+    EmuBackend be;
+    NftDiscSpec<EmuBackend> ds(be);
+    NftDsOpts o;
+    o.bsfilt = bsfilt; o.bsloc = bsloc; o.niter = niter; o.Dsub = Dsub; o.dstype = dstype;
+    o.nse_disc = nse_disc; o.richardson = richardson;
+    return ds.run(D, q, T, o, K_ptr, bound_states, nc);
 }
 
 }  // extern "C"

@@ -99,7 +99,10 @@ def test_unknown_and_unsupported_options(capi):
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == capi.FNFT_EC_OTHER
     # discrete spectrum requested
     bs = np.zeros(16, np.complex128)
-    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], bound_states=bs, K=16)[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], bound_states=bs, K=16)[0] == capi.FNFT_EC_OTHER  # needs the GPU
+    o = capi.default_opts()
+    o.bound_state_localization = 7
+    assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], bound_states=bs, K=16, opts=o)[0] == 2
     o = capi.default_opts()
     o.contspec_type = 7
     assert capi.fnft_nsev(q, [0, 1], 4, [-1, 1], opts=o)[0] == -2                # wrapped twice like the reference

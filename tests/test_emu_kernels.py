@@ -47,6 +47,8 @@ def emu():
                                   C.c_size_t, vp]
     L.emu_nsev_contspec.argtypes = [C.c_size_t, vp, vp, C.c_size_t, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.emu_kdvv_contspec.argtypes = [C.c_size_t, vp, vp, C.c_size_t, vp, vp, C.c_int]
+    L.emu_nsev_discspec.argtypes = [C.c_size_t, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                    C.c_int, C.POINTER(C.c_size_t), vp, vp]
     return L
 
 
@@ -168,3 +170,33 @@ def test_kdvv_vs_oracle(emu, oracle, fixtures, testcase, D, disc):
     assert rc2 == 0
     # order 5..8 schemes on coarse grids: ill-conditioned coefficient form, see signals.contspec_tol
     assert S.rel_err(out, ref) < (1e-9 if disc[6] in "5678" else 1e-11)
+
+
+@pytest.mark.parametrize("D,disc,bsloc", [(700, "2SPLIT2_MODAL", 2), (300, "2SPLIT4B", 2), (256, "2SPLIT4B", 0),
+                                          (128, "4SPLIT4A", 2), (256, "2SPLIT2A", 1)])
+def test_discrete_spectrum_vs_oracle(emu, oracle, fixtures, D, disc, bsloc):
+    """Bound states (Aberth root finder + chunk-parallel Newton), norming constants and residues in
+    the emulator against the oracle (numpy.roots + sequential scatterer) on the sech pulse."""
+    T = np.array([-25.0, 25.0])
+    q = S.sech_focusing(D)
+    K = C.c_size_t(4 * D)
+    bs = np.zeros(4 * D, np.complex128)
+    nc = np.zeros(8 * D, np.complex128)
+    loc = {0: "FAST_EIGENVALUE", 1: "NEWTON", 2: "SUBSAMPLE_AND_REFINE"}[bsloc]
+    guesses = np.array([0.6j, 1.8j, 2.6j])
+    if bsloc == 1:
+        bs[:3] = guesses
+        K = C.c_size_t(3)
+    rc = emu.emu_nsev_discspec(D, _P(q), _P(T), 2, bsloc, 10, 0, 2, NSE_DISC[disc], 0, C.byref(K), _P(bs), _P(nc))
+    assert rc == 0
+    k = K.value
+    rc2, bs_o, nc_o, res_o = oracle.fnft_nsev_ds(q, T, disc, bsloc=loc, guesses=guesses)
+    assert rc2 == 0 and k == bs_o.size == 3, (rc2, k, bs[:k], bs_o)
+    order = [int(np.argmin(np.abs(bs[:k] - v))) for v in bs_o]
+    assert sorted(order) == [0, 1, 2]
+    tol = 1e-6 if bsloc == 0 else 1e-10   # raw polynomial roots are conditioned like the polynomial
+    for j, i in enumerate(order):
+        assert abs(bs[i] - bs_o[j]) < tol
+        if bsloc != 0:
+            assert abs(nc[i] - nc_o[j]) < 1e-8 * abs(nc_o[j])
+            assert abs(nc[k + i] - res_o[j]) < 1e-8 * abs(res_o[j])

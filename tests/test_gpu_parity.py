@@ -453,3 +453,61 @@ def test_kdvv_cfg5_full_size(capi, oracle, fixtures):
     assert (M - 1) % 15 == 0
     assert S.rel_err(cs[idx], exact) < 1e-7
     plan.close()
+
+
+# ---- discrete spectrum (bound states, norming constants, residues) -------------------------------
+def _ds_cases():
+    return [c for c in _analytic_cases() if c.values[0]["testcase"] == "SECH_FOCUSING"
+            and np.isfinite(c.values[0]["stages"][0]["bounds_ds"][0])]
+
+
+@pytest.mark.parametrize("b", _ds_cases())
+def test_fnft_nsev_discrete_spectrum_bounds(capi, fixtures, b):
+    """Entries [3..5] of the reference's bounds (Hausdorff distance of the bound states, norming
+    constants, residues; fnft__nsev_testcases.c:650-700) for every harness call of the file, with the
+    harness's options: SUBSAMPLE_AND_REFINE, FULL filtering, 10 Newton steps, dstype BOTH, K = deg*D."""
+    fx = fixtures["nsev_sech_focusing"]
+    ex = [S.l2c(fx[k]) for k in ("bound_states", "normconsts", "residues")]
+    for st in b["stages"]:
+        out = capi.fnft_nsev_ds(S.sech_focusing(st["D"]), fx["T"], discretization=b["discretization"],
+                                richardson=bool(st["richardson"]), M=fx["M"], XI=fx["XI"])
+        rc, bs, nc, res = out[:4]
+        assert rc == 0, capi.last_error()
+        assert bs.size == 3, (st, bs)
+        errs = S.ds_errors(bs, nc, res, *ex)
+        for e, bound in zip(errs, st["bounds_ds"]):
+            if np.isfinite(bound):
+                assert e <= bound, (st, errs, b["file"])
+
+
+@pytest.mark.parametrize("D,disc,bsloc", [(1024, "2SPLIT4B", "SUBSAMPLE_AND_REFINE"), (1000, "2SPLIT2_MODAL", "FAST_EIGENVALUE"),
+                                          (512, "4SPLIT4B", "SUBSAMPLE_AND_REFINE"), (2048, "2SPLIT2A", "NEWTON"),
+                                          (1024, "2SPLIT3A", "SUBSAMPLE_AND_REFINE")])
+def test_discrete_spectrum_vs_oracle(capi, oracle, D, disc, bsloc):
+    T = [-25.0, 25.0]
+    q = S.sech_focusing(D) * np.exp(0.4j * S.tgrid(T, D))   # eigenvalues shifted off the imaginary axis
+    guesses = np.array([-0.2 + 0.6j, -0.2 + 1.8j, -0.2 + 2.6j]) if bsloc == "NEWTON" else None
+    rc, bs, nc, res = capi.fnft_nsev_ds(q, T, discretization=disc, bsloc=bsloc, guesses=guesses)
+    assert rc == 0, capi.last_error()
+    rc2, bs_o, nc_o, res_o = oracle.fnft_nsev_ds(q, T, disc, bsloc=bsloc, guesses=guesses)
+    assert rc2 == 0 and bs.size == bs_o.size == 3, (bs, bs_o)
+    tol = 1e-6 if bsloc == "FAST_EIGENVALUE" else 1e-10
+    for j in range(3):
+        i = int(np.argmin(np.abs(bs - bs_o[j])))
+        assert abs(bs[i] - bs_o[j]) < tol
+        if bsloc != "FAST_EIGENVALUE":
+            assert abs(nc[i] - nc_o[j]) < 1e-8 * abs(nc_o[j])
+            assert abs(res[i] - res_o[j]) < 1e-8 * abs(res_o[j])
+
+
+def test_discrete_spectrum_cfg4_full_size(capi, fixtures):
+    """BASELINE.json configs[3]: D = 2^20, default options (2SPLIT4B, SUBSAMPLE_AND_REFINE: roots of a
+    degree-40960 polynomial, Newton on all 2^20 samples), eigenvalues 0.7i, 1.7i, 2.7i."""
+    fx = fixtures["nsev_sech_focusing"]
+    D = 1 << 20
+    rc, bs, nc, res = capi.fnft_nsev_ds(S.sech_focusing(D), fx["T"], discretization="2SPLIT4B")
+    assert rc == 0, capi.last_error()
+    ex = [S.l2c(fx[k]) for k in ("bound_states", "normconsts", "residues")]
+    assert bs.size == 3, bs
+    errs = S.ds_errors(bs, nc, res, *ex)
+    assert errs[0] < 1e-9 and errs[1] < 1e-6 and errs[2] < 1e-6, errs
