@@ -162,10 +162,12 @@ FNFT_UINT fnft_nsev_max_K(const FNFT_UINT D, fnft_nsev_opts_t const *const opts)
 /* include/fnft_nsev.h:371-376.  All buffers are HOST memory owned by the caller:
  *   q[D]; T[2]; XI[2]; contspec[M], [2M] or [3M] by opts->contspec_type (NULL: skip);
  *   K_ptr / bound_states / normconsts_or_residues: discrete spectrum.
- * This build computes the continuous spectrum on the GPU.  A call that asks for the discrete
- * spectrum (kappa == +1 and bound_states != NULL) returns FNFT_EC_NOT_YET_IMPLEMENTED; every
- * other argument error returns the code the reference returns, checked in the same order
- * (src/fnft_nsev.c:163-220). */
+ * Continuous spectrum (all 21 fast discretizations, Richardson extrapolation) and discrete
+ * spectrum (kappa == +1 and bound_states != NULL: bound states by FAST_EIGENVALUE, NEWTON or
+ * SUBSAMPLE_AND_REFINE, filtering, norming constants / residues / both, *K_ptr = capacity in,
+ * count out) are computed on the GPU.  The slow discretizations (BO, CF*, ES4, TES4) return
+ * FNFT_EC_NOT_YET_IMPLEMENTED; argument errors return the codes the reference returns, checked
+ * in the same order (src/fnft_nsev.c:163-220). */
 FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *const T,
                    const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI,
                    FNFT_UINT *const K_ptr, FNFT_COMPLEX *const bound_states,
