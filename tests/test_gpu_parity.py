@@ -511,3 +511,26 @@ def test_discrete_spectrum_cfg4_full_size(capi, fixtures):
     assert bs.size == 3, bs
     errs = S.ds_errors(bs, nc, res, *ex)
     assert errs[0] < 1e-9 and errs[1] < 1e-6 and errs[2] < 1e-6, errs
+
+
+def test_reference_example_scenario(capi, oracle):
+    """The call of examples/fnft_nsev_example.c:32-76 -- rectangular pulse q = 2 on T = [-1, 1], D = 256,
+    M = 8, XI = [-2, 2], K = D, default options (2SPLIT4B, reflection coefficient, SUBSAMPLE_AND_REFINE,
+    norming constants) -- through the drop-in entry point: one bound state at 1.57423i."""
+    D, M = 256, 8
+    q = np.full(D, 2.0 + 0j)
+    T, XI = [-1.0, 1.0], [-2.0, 2.0]
+    opts = capi.default_opts()
+    K = D
+    bs = np.zeros(K, np.complex128)
+    nc = np.zeros(K, np.complex128)
+    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, opts=opts, bound_states=bs, K=K, normconsts=nc)
+    assert rc == 0, capi.last_error()
+    k = capi.fnft_nsev.last_K
+    assert k == 1
+    assert abs(bs[0] - 1.57423j) < 1e-5
+    rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc="2SPLIT4B", cstype="RHO")
+    assert rc2 == 0 and S.rel_err(cs, ref) < 1e-12
+    rc3, bs_o, nc_o, _ = oracle.fnft_nsev_ds(q, T, "2SPLIT4B")
+    assert rc3 == 0 and bs_o.size == 1
+    assert abs(bs[0] - bs_o[0]) < 1e-11 and abs(nc[0] - nc_o[0]) < 1e-9 * abs(nc_o[0])
