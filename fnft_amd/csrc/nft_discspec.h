@@ -17,7 +17,24 @@
 #include <memory>
 #include <vector>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "nft_plan.h"
+
+// optional stage log on stderr (FNFT_AMD_DS_TIMING=1), diagnostics only
+struct NftDsClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = std::getenv("FNFT_AMD_DS_TIMING") != nullptr;
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[discspec] %-28s %8.3f ms\n", what,
+                     std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 struct NftDsOpts {
     int bsfilt;        // fnft_nsev_bsfilt_t: 0 NONE, 1 BASIC, 2 FULL
@@ -219,6 +236,7 @@ public:
                 if (rc != NFT_SUCCESS) break;
                 double mc;
                 std::memcpy(&mc, &bits, sizeof(mc));
+                if (std::getenv("FNFT_AMD_DS_TIMING")) std::fprintf(stderr, "[aberth] n=%zu sweep %d max rel corr %.3e\n", n, it, mc);
                 if (mc < 4.0e-14) break;
             }
             if (rc == NFT_SUCCESS) {
@@ -356,18 +374,23 @@ public:
         Prepared full, sub;
         std::vector<cd> bs, nc, ap;
         NftDsOpts ob = o;
+        NftDsClock clk;
         if (o.richardson && o.dstype == 1) ob.dstype = 2;   // residues need norming constants too, :248-258
         int rc = prepare(D, q, T, D, o.nse_disc, full);
+        clk.lap("prepare(full)");
         if (rc == NFT_SUCCESS) {
             if (o.bsloc == 2) {   // SUBSAMPLE_AND_REFINE, :276-304
                 size_t Dsub = o.Dsub;
                 if (Dsub == 0) Dsub = (size_t)std::sqrt((double)D * std::log2((double)D) * std::log2((double)D));
                 rc = prepare(D, q, T, Dsub, o.nse_disc, sub);
+                clk.lap("prepare(sub)");
                 if (rc == NFT_SUCCESS) rc = base(sub, ob, 0, bs, nullptr, nullptr);
+                clk.lap("roots + filter (sub)");
                 release(sub);
                 if (rc == NFT_SUCCESS && bs.size() > *K_ptr) { warn_more_than_K = 1; bs.resize(*K_ptr); }
                 if (rc == NFT_SUCCESS)
                     rc = base(full, ob, 1, bs, normconsts_or_residues ? &nc : nullptr, &ap);
+                clk.lap("newton + normconsts (full)");
             } else {
                 if (o.bsloc == 1) bs.assign(bound_states, bound_states + *K_ptr);
                 rc = base(full, ob, o.bsloc, bs, normconsts_or_residues ? &nc : nullptr, &ap);

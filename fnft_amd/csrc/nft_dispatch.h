@@ -69,8 +69,8 @@ struct KBsPick {
 struct KAberthNewton {
     using Params = AberthParams;
     static constexpr int THREADS = 64;
-    static constexpr size_t lds_bytes() { return 0; }
-    static FA_DEV void body(const Params &p) { body_aberth_newton(p); }
+    static constexpr size_t lds_bytes() { return 2 * 1024 * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_aberth_newton<1024>(p); }
 };
 struct KAberthUpdate {
     using Params = AberthParams;

@@ -1869,33 +1869,59 @@ struct AberthParams {
     unsigned long long *maxcorr;   // bits of max |corr|/|z| of the sweep
 };
 
-FA_DEV void body_aberth_newton(const AberthParams &P)
+// p(x) = sum_r x^r P_r(x^4): four independent Horner chains (plus their derivatives) per lane, the
+// coefficients staged through LDS in tiles that the workgroup loads together.  asc(k) is the
+// coefficient of x^k: x = z reads coef[n-k], x = 1/z (|z| > 1) reads coef[k].
+template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
 {
+    FA_LDS_DECL
+    cplx *tile = (cplx *)FA_LDS_PTR;
     const long long k = (long long)FA_BID * FA_BDIM + FA_TID;
-    if (k >= P.n) return;
-    const cplx z = P.z[k];
     const long long n = P.n;
-    cplx w;
-    if (cnorm2(z) <= 1.0) {
-        cplx p = P.coef[0], dp = cmake(0.0, 0.0);
-        for (long long j = 1; j <= n; j++) {
-            dp = dp * z + p;
-            p = p * z + P.coef[j];
+    const bool act = k < n;
+    const cplx z = act ? P.z[k] : cmake(0.5, 0.0);
+    const bool inside = cnorm2(z) <= 1.0;
+    const cplx x = inside ? z : c_div(cmake(1.0, 0.0), z);
+    const cplx x2 = x * x, w = x2 * x2;
+    cplx p0 = cmake(0.0, 0.0), p1 = p0, p2 = p0, p3 = p0, d0 = p0, d1 = p0, d2 = p0, d3 = p0;
+    // powers run from the top block (m = Mtop) down to m = 0; block m holds powers 4m .. 4m+3
+    const long long Mtop = n / 4;
+    for (long long mhi = Mtop; mhi >= 0; mhi -= TILE / 4) {
+        const long long mlo = (mhi - TILE / 4 + 1 > 0) ? mhi - TILE / 4 + 1 : 0;
+        const long long kbase = 4 * mlo;            // lowest power held by this tile
+        FA_SYNC();
+        for (int t = FA_TID; t < TILE; t += FA_BDIM) {
+            const long long kk = kbase + t;
+            // both orientations are needed inside one workgroup: interleave them
+            tile[2 * t] = (kk <= n) ? P.coef[n - kk] : cmake(0.0, 0.0);
+            tile[2 * t + 1] = (kk <= n) ? P.coef[kk] : cmake(0.0, 0.0);
         }
-        w = c_div(p, dp);
-    } else {
-        const cplx y = c_div(cmake(1.0, 0.0), z);
-        cplx p = P.coef[n], dp = cmake(0.0, 0.0);
-        for (long long j = 1; j <= n; j++) {
-            dp = dp * y + p;
-            p = p * y + P.coef[n - j];
+        FA_SYNC();
+        const int off = inside ? 0 : 1;
+        for (long long m = mhi; m >= mlo; m--) {
+            const int t = (int)(4 * (m - mlo));
+            d0 = d0 * w + p0; p0 = p0 * w + tile[2 * t + off];
+            d1 = d1 * w + p1; p1 = p1 * w + tile[2 * (t + 1) + off];
+            d2 = d2 * w + p2; p2 = p2 * w + tile[2 * (t + 2) + off];
+            d3 = d3 * w + p3; p3 = p3 * w + tile[2 * (t + 3) + off];
         }
-        // p(z) = z^n q(y):  p'/p = n/z - y^2 q'(y)/q(y)
-        const cplx t = y * (double)n - (y * y) * c_div(dp, p);
-        w = c_div(cmake(1.0, 0.0), t);
     }
-    if (!(w.x == w.x) || !(w.y == w.y) || fabs(w.x) > 1.0e300 || fabs(w.y) > 1.0e300) w = cmake(0.0, 0.0);
-    P.w[k] = w;
+    if (!act) return;
+    // p = P0 + x P1 + x^2 P2 + x^3 P3;  p' = P1 + 2x P2 + 3x^2 P3 + 4x^3 (P0' + x P1' + x^2 P2' + x^3 P3')
+    const cplx x3 = x2 * x;
+    const cplx p = p0 + x * p1 + x2 * p2 + x3 * p3;
+    const cplx dsum = d0 + x * d1 + x2 * d2 + x3 * d3;
+    const cplx dp = p1 + (x * p2) * 2.0 + (x2 * p3) * 3.0 + (x3 * dsum) * 4.0;
+    cplx wv;
+    if (inside) {
+        wv = c_div(p, dp);
+    } else {
+        // p(z) = z^n q(y), y = 1/z:  p'/p = n/z - y^2 q'(y)/q(y)
+        const cplx t = x * (double)n - x2 * c_div(dp, p);
+        wv = c_div(cmake(1.0, 0.0), t);
+    }
+    if (!(wv.x == wv.x) || !(wv.y == wv.y) || fabs(wv.x) > 1.0e300 || fabs(wv.y) > 1.0e300) wv = cmake(0.0, 0.0);
+    P.w[k] = wv;
 }
 
 template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
@@ -1911,10 +1937,28 @@ template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
         if (j0 + FA_TID < P.n) tile[FA_TID] = P.z[j0 + FA_TID];
         FA_SYNC();
         const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
-        if (act)
-            for (int j = 0; j < lim; j++)
-                if (j0 + j != k) s = s + c_div(cmake(1.0, 0.0), zk - tile[j]);
+        if (act) {
+            // 1/(zk - zj) = conj(d)/|d|^2; the own term is replaced by 1/(1 + 0i) and taken out below
+            cplx s1 = cmake(0.0, 0.0);
+            int j = 0;
+            for (; j + 1 < lim; j += 2) {
+                cplx da = zk - tile[j], db = zk - tile[j + 1];
+                if (j0 + j == k) da = cmake(1.0, 0.0);
+                if (j0 + j + 1 == k) db = cmake(1.0, 0.0);
+                const double ia = 1.0 / cnorm2(da), ib = 1.0 / cnorm2(db);
+                s = s + cmake(da.x * ia, -da.y * ia);
+                s1 = s1 + cmake(db.x * ib, -db.y * ib);
+            }
+            if (j < lim) {
+                cplx da = zk - tile[j];
+                if (j0 + j == k) da = cmake(1.0, 0.0);
+                const double ia = 1.0 / cnorm2(da);
+                s = s + cmake(da.x * ia, -da.y * ia);
+            }
+            s = s + s1;
+        }
     }
+    s = s - cmake(1.0, 0.0);
     FA_SYNC();
     double rel = 0.0;
     if (act) {
