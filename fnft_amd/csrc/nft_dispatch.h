@@ -6,7 +6,10 @@
 #pragma once
 #include "nft_kernels.h"
 
-constexpr int kRowTree = 2048;      // N2 of the split transforms of the product tree
+#ifndef FA_ROW_TREE
+#define FA_ROW_TREE 2048
+#endif
+constexpr int kRowTree = FA_ROW_TREE;      // N2 of the split transforms of the product tree
 constexpr int kRowChirp = 4096;     // N2 of the split transforms of the chirp z-transform
 constexpr int kFusedMaxN = 4096;    // largest pair product done by one workgroup
 constexpr int kSchoolMaxDeg = 3;    // direct products up to this input degree
@@ -196,19 +199,19 @@ template <int NE> struct KMid {
     static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_mid<kRowTree, R, NE>(p); }
 };
-template <int N1> struct KChirpColFwd {
+template <int N1, bool DFT = false> struct KChirpColFwd {
     using Params = ChirpParams;
     using C = ColCfg<N1>;
     static constexpr int THREADS = C::THREADS;
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
-    static FA_DEV void body(const Params &p) { body_chirp_col_fwd<N1, C::R, C::BC, C::DB>(p); }
+    static FA_DEV void body(const Params &p) { body_chirp_col_fwd<N1, C::R, C::BC, C::DB, DFT>(p); }
 };
-template <int N1> struct KChirpColInv {
+template <int N1, bool DFT = false> struct KChirpColInv {
     using Params = ChirpParams;
     using C = ColCfg<N1>;
     static constexpr int THREADS = C::THREADS;
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
-    static FA_DEV void body(const Params &p) { body_chirp_col_inv<N1, C::R, C::BC, C::DB>(p); }
+    static FA_DEV void body(const Params &p) { body_chirp_col_inv<N1, C::R, C::BC, C::DB, DFT>(p); }
 };
 struct KChirpRows {
     using Params = ChirpParams;
@@ -345,9 +348,9 @@ template <class BE> bool dispatch_col_bridge2(BE &be, const BigLevel &G)
 }
 template <class BE> bool dispatch_chirp_col_fwd(BE &be, const ChirpParams &C)
 {
-    const int jobs = C.batch * C.npoly + 1;
+    const int jobs = C.batch * C.npoly + (C.v_mode == 2 ? 0 : 1);   // the filter job is skipped when its spectrum is cached
     switch (C.N1) {
-#define X(n1) case n1: be.template run<KChirpColFwd<n1>>(C.N2 / ColCfg<n1>::BC, jobs, C); return true;
+#define X(n1) case n1: if (C.dft_len > 0) be.template run<KChirpColFwd<n1, true>>(C.N2 / ColCfg<n1>::BC, jobs, C); else be.template run<KChirpColFwd<n1>>(C.N2 / ColCfg<n1>::BC, jobs, C); return true;
         FA_FOR_EACH_N1(X)
 #undef X
     default: return false;
@@ -356,7 +359,7 @@ template <class BE> bool dispatch_chirp_col_fwd(BE &be, const ChirpParams &C)
 template <class BE> bool dispatch_chirp_col_inv(BE &be, const ChirpParams &C)
 {
     switch (C.N1) {
-#define X(n1) case n1: be.template run<KChirpColInv<n1>>(C.N2 / ColCfg<n1>::BC, C.batch, C); return true;
+#define X(n1) case n1: if (C.dft_len > 0) be.template run<KChirpColInv<n1, true>>(C.N2 / ColCfg<n1>::BC, C.batch, C); else be.template run<KChirpColInv<n1>>(C.N2 / ColCfg<n1>::BC, C.batch, C); return true;
         FA_FOR_EACH_N1(X)
 #undef X
     default: return false;

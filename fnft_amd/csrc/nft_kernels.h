@@ -1350,6 +1350,10 @@ struct ChirpParams {
     // residue, and poly holds coefficients in ascending order (x[n] multiplies z^n)
     long long dft_len;   // 0: off
     int dft_sign;
+    // spectrum of the chirp filter v (depends on W, M, deg and the transform length only): kept
+    // between calls with the same grids.  v_mode 0: compute; 1: compute and store; 2: load
+    cplx *VS;
+    int v_mode;
 };
 
 // exp((xr + i*xi)) with a real multiplier folded in: returns exp(t*lr) * cis(t*li)
@@ -1378,9 +1382,9 @@ FA_DEV cplx cpow_real2(const double la[2], double ta, const double lw[2], double
 }
 
 // W^(half * n^2), half = +-0.5
-FA_DEV cplx chirp_w(const ChirpParams &C, long long n, double half)
+template <bool DFT> FA_DEV cplx chirp_w(const ChirpParams &C, long long n, double half)
 {
-    if (C.dft_len > 0) {
+    if (DFT) {
         const unsigned long long r = ((unsigned long long)n * (unsigned long long)n)
                                      % (2ull * (unsigned long long)C.dft_len);
         double s, c;
@@ -1392,10 +1396,10 @@ FA_DEV cplx chirp_w(const ChirpParams &C, long long n, double half)
     return cpow_real(C.logW, half * dn * dn);
 }
 
-FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k)
+template <bool DFT> FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k)
 {
     // coefficient k (highest power first) of polynomial `slot` of signal b
-    if (C.poly && C.dft_len > 0)
+    if (DFT)
         return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)(C.deg - k)];
     if (C.poly) return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)k];
     return stored_coef(C.body, C.tail, C.plane, C.deg_tot, C.deg, C.batch, C.ne, C.entry[slot], b, k)
@@ -1404,7 +1408,7 @@ FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k)
 
 // column step (forward) of the chirp-premultiplied polynomials and of the chirp filter
 //   grid.x = N2/BC, grid.y = batch*npoly + 1 (the last one is the filter v)
-template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_fwd(const ChirpParams &C)
+template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_fwd(const ChirpParams &C)
 {
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
@@ -1424,13 +1428,13 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_fwd(const C
         const double dn = (double)n;
         if (job < njobs) {
             if (n < Np) {  // :68-69  p[deg-n] * A^-n * W^(n^2/2)
-                const cplx pc = chirp_poly_coef(C, job / C.npoly, job % C.npoly, C.deg - n);
-                val = (C.dft_len > 0) ? pc * chirp_w(C, n, 0.5)
-                                      : pc * cpow_real2(C.logA, -dn, C.logW, 0.5 * dn * dn);
+                const cplx pc = chirp_poly_coef<DFT>(C, job / C.npoly, job % C.npoly, C.deg - n);
+                val = DFT ? pc * chirp_w<true>(C, n, 0.5)
+                          : pc * cpow_real2(C.logA, -dn, C.logW, 0.5 * dn * dn);
             }
         } else {  // :76-82
-            if (n < C.M) val = chirp_w(C, n, -0.5);
-            else if (n > Lc - Np) val = chirp_w(C, Lc - n, -0.5);
+            if (n < C.M) val = chirp_w<DFT>(C, n, -0.5);
+            else if (n > Lc - Np) val = chirp_w<DFT>(C, Lc - n, -0.5);
         }
         x[i] = val;
     }
@@ -1462,10 +1466,21 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
 #pragma unroll
     for (int i = 1; i < R; i++) tw[i] = base * big_twiddle(C.btw, (unsigned)k1 * (unsigned)((N2 / R) * i));
     cplx vv[R];
-    const cplx *vs = C.Vbuf + (size_t)k1 * N2;
+    if (C.v_mode == 2) {
+        const cplx *vs = C.VS + (size_t)k1 * N2;
 #pragma unroll
-    for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i] * tw[i];
-    fft_wg<N2, R, 1, -1, DB>(vv, lds, v, 0, C.tw2, parity);
+        for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i];
+    } else {
+        const cplx *vs = C.Vbuf + (size_t)k1 * N2;
+#pragma unroll
+        for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i] * tw[i];
+        fft_wg<N2, R, 1, -1, DB>(vv, lds, v, 0, C.tw2, parity);
+        if (C.v_mode == 1 && FA_BID_Y == 0) {
+            cplx *vd = C.VS + (size_t)k1 * N2;
+#pragma unroll
+            for (int i = 0; i < R; i++) vd[v + (N2 / R) * i] = vv[i];
+        }
+    }
     const int njobs = C.batch * C.npoly;
     const double inv = 1.0 / (double)N2;
     const int job0 = FA_BID_Y * C.jobs_per_group;
@@ -1486,7 +1501,7 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
 
 // column step (inverse) + chirp post-multiplication + spectrum epilogue
 //   grid.x = N2/BC, grid.y = batch
-template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const ChirpParams &C)
+template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_inv(const ChirpParams &C)
 {
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
@@ -1529,7 +1544,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_chirp_col_inv(const C
         const long long m = (long long)n1 * C.N2 + n2;
         if (m >= C.M) continue;
         {   // :94-95  result[m] = W^(m^2/2) * V[m] / L
-            const cplx cw = chirp_w(C, m, 0.5);
+            const cplx cw = chirp_w<DFT>(C, m, 0.5);
             H[0][i] = H[0][i] * cw;
             H[1][i] = H[1][i] * cw;
         }

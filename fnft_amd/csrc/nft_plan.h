@@ -140,6 +140,9 @@ public:
     size_t Lr = 0;
     cplx *Y = nullptr, *Z = nullptr, *Z2 = nullptr;   // Z ping-pongs when spectral doubling is on
     cplx *chY = nullptr, *chV = nullptr, *chH = nullptr;
+    cplx *chVS = nullptr;                 // cached spectrum of the chirp filter
+    double vs_key[4] = {0, 0, 0, 0};      // log W (re, im), M, deg+1 it was computed for
+    bool vs_valid = false;
     cplx *tm_out = nullptr;
     cplx *twtab = nullptr;   // concatenated tables for N = 2,4,...,kMaxTwTable
     cplx *twlo = nullptr;    // exp(-2 pi i j / 2^24), j < 4096
@@ -227,7 +230,7 @@ public:
             Lc = nft_nextpow2(Np + M - 1);
             if (Lc < 2 * (size_t)kRowChirp) Lc = 2 * (size_t)kRowChirp;
             if (Lc > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
-            ok = ok && alloc(chY, batch * 2 * Lc) && alloc(chV, Lc);
+            ok = ok && alloc(chY, batch * 2 * Lc) && alloc(chV, Lc) && alloc(chVS, Lc);
         }
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
         ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
@@ -269,7 +272,7 @@ public:
     {
         for (int i = 0; i < 2; i++) { be.free(body[i]); be.free(tail[i]); be.free(scale[i]); be.free(wexp[i]); }
         be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
-        be.free(chY); be.free(chV); be.free(chH); be.free(tm_out); be.free(twtab); be.free(twlo);
+        be.free(chY); be.free(chV); be.free(chH); be.free(chVS); be.free(tm_out); be.free(twtab); be.free(twlo);
         be.free(prog_bfrac); be.free(prog_mw); be.free(prog_ptr); be.free(prog_fac);
         be.free(rneg);
         be.free(qpre); be.free(rsX); be.free(rsX12); be.free(rsQ12); be.free(rsY); be.free(rsV);
@@ -591,7 +594,7 @@ public:
                  + (shifted ? eps_t / deg1 : 0.0);
         C.cstype = cs.cstype;
         C.use_W = 1;  // W is the exponent actually taken out, whatever normalization_flag says
-        return run_chirp(C);
+        return run_chirp_cached(C);
     }
 
     // fnft_kdvv.c:126-209 (tf2contspec_negxi): entries 12 and 22 on the grid -(XI0 + m*eps_xi)
@@ -630,7 +633,20 @@ public:
         C.pf_rho = 2.0 * (T[1] + 0.5 * eps_t);          // :199, boundary coefficient 0.5
         C.pf_a = scheme_2A ? -eps_t / deg1 : 0.0;       // :186-195
         C.cstype = 10;
-        return run_chirp(C);
+        return run_chirp_cached(C);
+    }
+
+    // the spectrum of the chirp filter only depends on W, M, the degree and the transform length:
+    // repeated transforms on the same grids (T, XI fixed) reuse it
+    int run_chirp_cached(ChirpParams &C)
+    {
+        const double key[4] = {C.logW[0], C.logW[1], (double)C.M, (double)(C.deg + 1)};
+        const bool hit = vs_valid && std::memcmp(key, vs_key, sizeof(key)) == 0;
+        C.VS = chVS;
+        C.v_mode = hit ? 2 : 1;
+        const int rc = run_chirp(C);
+        if (rc == NFT_SUCCESS) { std::memcpy(vs_key, key, sizeof(key)); vs_valid = true; }
+        return rc;
     }
 
     int run_chirp(const ChirpParams &C)
