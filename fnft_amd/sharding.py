@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of independent signals (one process per GPU, torch.distributed).
+"""Multi-GPU sharding of independent signals and of the xi-grid (one process per GPU, torch.distributed).
 
 The fnft_nsev hot path has no cross-signal dependency: a batch of B
 signals is cut into contiguous shards, every rank transforms its shard with no communication,
@@ -84,3 +84,45 @@ def transform_batch(signals: Optional[np.ndarray], n_signals: int,
     shard = recv[: hi - lo].numpy().reshape(hi - lo, D * 2).view(np.complex128)
     out = compute(shard, lo)
     return gather_shards(out, n_signals, dst=dst, group=group)
+
+
+# ---- one signal, spectral grid cut into contiguous slices --------------
+def xi_shard(XI, M: int, world: int, rank: int):
+    """Slice of the grid xi_m = XI[0] + m*eps_xi, m < M, owned by `rank`:
+    returns ([xi_lo, xi_hi], M_local, first_index).  Every rank needs at least two points (the
+    transform takes the grid as end points + count, include/fnft_nsev.h:371-376)."""
+    if M < 2 * world:
+        raise ValueError("xi-grid sharding needs M >= 2*world")
+    lo, hi = shard_range(M, world, rank)
+    eps_xi = (XI[1] - XI[0]) / (M - 1)
+    return [XI[0] + lo * eps_xi, XI[0] + (hi - 1) * eps_xi], hi - lo, lo
+
+
+def transform_xi_grid(q: Optional[np.ndarray], T, XI, M: int,
+                      compute: Callable[[np.ndarray, list, list, int], np.ndarray], dst: int = 0, group=None):
+    """Root holds the signal q [D] complex128 (others pass None).  The signal is broadcast, rank r
+    evaluates `compute(q, T, XI_r, M_r)` -> complex array [n_parts, M_r] (n_parts = 1, 2 or 3 blocks
+    of the reference's contspec layout) on its slice of the grid, and the slices meet in one gather on
+    the root, which returns the [n_parts * M] contspec in the reference's layout (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    meta = [int(q.shape[0])] if rank == dst else [None]
+    dist.broadcast_object_list(meta, src=dst, group=group)
+    D = meta[0]
+    buf = torch.zeros((D, 2), dtype=torch.float64)
+    if rank == dst:
+        buf.copy_(torch.from_numpy(np.ascontiguousarray(q).view(np.float64).reshape(D, 2)))
+    dist.broadcast(buf, src=dst, group=group)
+    qq = buf.numpy().reshape(2 * D).view(np.complex128)
+    XI_r, M_r, _ = xi_shard(XI, M, world, rank)
+    part = np.asarray(compute(qq, list(T), XI_r, M_r), np.complex128)
+    n_parts = part.shape[0]
+    rows = torch.from_numpy(np.ascontiguousarray(part.T).view(np.float64).reshape(M_r, 2 * n_parts))
+    full = gather_shards(rows, M, dst=dst, group=group)
+    if full is None:
+        return None
+    arr = full.numpy().reshape(M, 2 * n_parts).view(np.complex128)   # [M, n_parts]
+    return np.ascontiguousarray(arr.T).reshape(n_parts * M)

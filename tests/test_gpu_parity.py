@@ -534,3 +534,23 @@ def test_reference_example_scenario(capi, oracle):
     rc3, bs_o, nc_o, _ = oracle.fnft_nsev_ds(q, T, "2SPLIT4B")
     assert rc3 == 0 and bs_o.size == 1
     assert abs(bs[0] - bs_o[0]) < 1e-11 and abs(nc[0] - nc_o[0]) < 1e-9 * abs(nc_o[0])
+
+
+def test_xi_grid_slices_match_full_grid(capi):
+    """SURVEY 8e-iii on one GPU: the slices a 4-rank job would evaluate, computed one after the other,
+    against the transform on the full grid (the chirp parameters A, V differ per slice, so equality is
+    to round-off, not bit-exact)."""
+    from fnft_amd import sharding
+    D, M = 4096, 1000
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    q = S.sech_focusing(D)
+    rc, full = capi.fnft_nsev(q, T, M, XI, discretization="2SPLIT4B", contspec_type="BOTH")
+    assert rc == 0
+    full = full.reshape(3, M)
+    for r in range(4):
+        XI_r, M_r, lo = sharding.xi_shard(XI, M, 4, r)
+        rc, part = capi.fnft_nsev(q, T, M_r, XI_r, discretization="2SPLIT4B", contspec_type="BOTH")
+        assert rc == 0
+        part = part.reshape(3, M_r)
+        for j in range(3):
+            assert S.rel_err(part[j], full[j, lo:lo + M_r]) < 1e-11

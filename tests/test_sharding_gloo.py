@@ -3,6 +3,7 @@ single gather and the root-side ordering.  The per-shard compute is a stand-in (
 CPU path); what is checked is that row k of the gathered result is the result of signal k."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -72,3 +73,58 @@ def test_scatter_compute_gather(world, n_signals):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(results)
+
+
+# ---- xi-grid sharding of one signal, oracle as the per-rank engine ----------------
+def _oracle_slice(q, T, XI_r, M_r):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import load_oracle
+    rc, cs = load_oracle().fnft_nsev(q, T, M_r, XI_r, kappa=1, disc="2SPLIT4B", cstype="BOTH")
+    assert rc == 0
+    return cs.reshape(3, M_r)
+
+
+def _xi_worker(rank, world, port, D, M, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T, XI = [-25.0, 25.0], [-1.4, 1.6]
+        t = T[0] + np.arange(D) * (T[1] - T[0]) / (D - 1)
+        sig = (3.2j / np.cosh(t)).astype(np.complex128) if rank == 0 else None
+        res = sharding.transform_xi_grid(sig, T, XI, M, _oracle_slice, dst=0)
+        if rank == 0:
+            ref = _oracle_slice(sig, T, XI, M).reshape(3 * M)
+            err = float(np.sum(np.abs(res - ref)) / np.sum(np.abs(ref)))
+            q.put(err < 1e-12 and res.shape == (3 * M,))
+        else:
+            q.put(res is None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,M", [(2, 37), (3, 16)])
+def test_xi_grid_sharding(world, M):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xi_worker, args=(r, world, port, 256, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results)
+
+
+def test_xi_shard_ranges():
+    XI, M = [-1.4, 1.6], 37
+    eps = (XI[1] - XI[0]) / (M - 1)
+    pts = []
+    for r in range(3):
+        xr, mr, lo = sharding.xi_shard(XI, M, 3, r)
+        pts += list(xr[0] + np.arange(mr) * (xr[1] - xr[0]) / (mr - 1))
+    assert np.allclose(pts, XI[0] + np.arange(M) * eps, atol=1e-15)
+    with pytest.raises(ValueError):
+        sharding.xi_shard(XI, 5, 3, 0)
