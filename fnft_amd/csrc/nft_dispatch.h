@@ -206,12 +206,12 @@ template <int N1, bool DFT = false> struct KChirpColFwd {
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
     static FA_DEV void body(const Params &p) { body_chirp_col_fwd<N1, C::R, C::BC, C::DB, DFT>(p); }
 };
-template <int N1, bool DFT = false> struct KChirpColInv {
+template <int N1, bool DFT = false, bool KDV = false> struct KChirpColInv {
     using Params = ChirpParams;
     using C = ColCfg<N1>;
     static constexpr int THREADS = C::THREADS;
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
-    static FA_DEV void body(const Params &p) { body_chirp_col_inv<N1, C::R, C::BC, C::DB, DFT>(p); }
+    static FA_DEV void body(const Params &p) { body_chirp_col_inv<N1, C::R, C::BC, C::DB, DFT, KDV>(p); }
 };
 struct KChirpRows {
     using Params = ChirpParams;
@@ -359,7 +359,7 @@ template <class BE> bool dispatch_chirp_col_fwd(BE &be, const ChirpParams &C)
 template <class BE> bool dispatch_chirp_col_inv(BE &be, const ChirpParams &C)
 {
     switch (C.N1) {
-#define X(n1) case n1: if (C.dft_len > 0) be.template run<KChirpColInv<n1, true>>(C.N2 / ColCfg<n1>::BC, C.batch, C); else be.template run<KChirpColInv<n1>>(C.N2 / ColCfg<n1>::BC, C.batch, C); return true;
+#define X(n1) case n1: if (C.dft_len > 0) be.template run<KChirpColInv<n1, true>>(C.N2 / ColCfg<n1>::BC, C.batch, C); else if (C.cstype == 10) be.template run<KChirpColInv<n1, false, true>>(C.N2 / ColCfg<n1>::BC, C.batch, C); else be.template run<KChirpColInv<n1>>(C.N2 / ColCfg<n1>::BC, C.batch, C); return true;
         FA_FOR_EACH_N1(X)
 #undef X
     default: return false;

@@ -1501,7 +1501,7 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
 
 // column step (inverse) + chirp post-multiplication + spectrum epilogue
 //   grid.x = N2/BC, grid.y = batch
-template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_inv(const ChirpParams &C)
+template <int N1, int R, int BC, bool DB, bool DFT, bool KDV> FA_DEV void body_chirp_col_inv(const ChirpParams &C)
 {
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
@@ -1556,7 +1556,7 @@ template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_i
             continue;
         }
         const double xi = C.xi0 + C.eps_xi * (double)m;  // fnft_nsev.c:784-785
-        if (C.cstype == 10) {
+        if (KDV) {
             // KdV reflection coefficient, fnft_kdvv.c:186-203: slots hold H12 and H22, xi runs over
             // -(XI0 + m*eps_xi); pf_a = -eps_t/deg undoes the 2SPLIT2A base change (else 0),
             // pf_rho = 2*(T1 + eps_t/2).  No zero test: the reference divides unguarded.

@@ -538,8 +538,10 @@ def test_reference_example_scenario(capi, oracle):
 
 def test_xi_grid_slices_match_full_grid(capi):
     """SURVEY 8e-iii on one GPU: the slices a 4-rank job would evaluate, computed one after the other,
-    against the transform on the full grid (the chirp parameters A, V differ per slice, so equality is
-    to round-off, not bit-exact)."""
+    against the transform on the full grid.  The chirp parameters A, V differ per slice, and the
+    reference's evaluation points z_m = V^m / A drift off the unit circle by m*1.1e-16 (see
+    test_batch_cfg3_shard), a drift the slices restart at their first point: the two agree within
+    deg * M * 2.2e-16, not to the last bit."""
     from fnft_amd import sharding
     D, M = 4096, 1000
     T, XI = [-25.0, 25.0], [-1.4, 1.6]
@@ -553,4 +555,4 @@ def test_xi_grid_slices_match_full_grid(capi):
         assert rc == 0
         part = part.reshape(3, M_r)
         for j in range(3):
-            assert S.rel_err(part[j], full[j, lo:lo + M_r]) < 1e-11
+            assert S.rel_err(part[j], full[j, lo:lo + M_r]) < 2 * D * M * 2.2e-16
