@@ -15,6 +15,9 @@
 #include "../../include/fnft_amd.h"
 
 static thread_local std::string g_last_error;
+// Host-pointer entry points share cached plans and workspaces: one call at a time (SURVEY 8b allows an
+// internal mutex); device-resident plans are independent objects with their own lock.
+static std::mutex g_host_call_mtx;
 
 static bool hip_ok(hipError_t e, const char *what)
 {
@@ -413,6 +416,7 @@ FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, cons
 FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const FNFT_REAL *T, FNFT_UINT M,
                                       FNFT_COMPLEX *contspec, const FNFT_REAL *XI, int discretization)
 {
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
     static std::mutex cache_mtx;
     static std::map<std::tuple<size_t, size_t, int>, fnft_amd_plan *> cache;
     if (!ensure_device(0)) return FNFT_EC_OTHER;
@@ -458,6 +462,7 @@ FNFT_INT fnft_amd__nsev_discspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                                       int richardson, FNFT_UINT *K_ptr, FNFT_COMPLEX *bound_states,
                                       FNFT_COMPLEX *normconsts_or_residues, int *warn)
 {
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
     if (!ensure_device(0)) return FNFT_EC_OTHER;
     HipBackend be;
     NftDiscSpec<HipBackend> ds(be);
@@ -482,6 +487,7 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                                       FNFT_INT kappa, int discretization, int contspec_type,
                                       FNFT_INT normalization_flag, FNFT_UINT nskip)
 {
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
     static std::mutex cache_mtx;
     static std::map<std::tuple<size_t, size_t, int, size_t>, fnft_amd_plan *> cache;
     if (!ensure_device(0)) return FNFT_EC_OTHER;

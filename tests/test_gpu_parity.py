@@ -556,3 +556,43 @@ def test_xi_grid_slices_match_full_grid(capi):
         part = part.reshape(3, M_r)
         for j in range(3):
             assert S.rel_err(part[j], full[j, lo:lo + M_r]) < 2 * D * M * 2.2e-16
+
+
+def test_concurrent_host_threads(capi, oracle):
+    """SURVEY 8b threading contract: the drop-in entry points may be called from several host threads
+    at once (own opts per thread).  ctypes releases the GIL, so these calls really overlap; every
+    result is checked against the oracle."""
+    import threading
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    jobs = [(1024, 64, "2SPLIT4B"), (1000, 50, "2SPLIT2_MODAL"), (2048, 128, "2SPLIT3A"), (512, 33, "4SPLIT4B"),
+            (1024, 64, "2SPLIT4B"), (777, 20, "2SPLIT2A")]
+    out = [None] * len(jobs)
+
+    def work(i):
+        D, M, disc = jobs[i]
+        q = S.sech_focusing(D, amp=2.0 + 0.2 * i)
+        res = []
+        for _ in range(3):
+            rc, cs = capi.fnft_nsev(q, T, M, XI, discretization=disc, contspec_type="BOTH")
+            res.append((rc, cs))
+        rc_d, bs, nc, resd = capi.fnft_nsev_ds(q, T, discretization=disc) if i % 2 == 0 else (0, None, None, None)
+        out[i] = (q, res, rc_d, bs)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for i, (D, M, disc) in enumerate(jobs):
+        q, res, rc_d, bs = out[i]
+        rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc=disc, cstype="BOTH")
+        assert rc2 == 0
+        for rc, cs in res:
+            assert rc == 0, capi.last_error()
+            assert S.rel_err(cs, ref) < 1e-11, (i, disc)
+        assert rc_d == 0
+        if bs is not None:
+            rc3, bs_o, _, _ = oracle.fnft_nsev_ds(q, T, disc)
+            assert rc3 == 0 and bs.size == bs_o.size
+            for v in bs_o:
+                assert np.min(np.abs(bs - v)) < 1e-9
