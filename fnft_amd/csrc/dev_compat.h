@@ -38,6 +38,13 @@ FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+// value known to be the same in every lane of the wave: move it to scalar registers
+FA_DEV double fa_uniform(double x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 #else
 // ------------------------------------------------------------------------------------------
 #include <barrier>
@@ -74,6 +81,7 @@ FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
+FA_DEV double fa_uniform(double x) { return x; }
 using std::exp;
 using std::floor;
 using std::fma;

@@ -913,10 +913,19 @@ template <int N2, int R> struct MidIO {
     long long P;
     int k1;
     double sc[2];
+    cplx wu[R];   // workgroup-uniform factors w^{k1 (N2/R) i}: scalar registers
+    cplx wbase;   // per-lane w^{k1 v}
     FA_DEV MidIO(const BigLevel &G_) : G(G_)
     {
         P = FA_BID / G.N1;
         k1 = FA_BID % G.N1;
+#pragma unroll
+        for (int i = 1; i < R; i++) {
+            const cplx w = big_twiddle(G.btw, (unsigned)k1 * (unsigned)((N2 / R) * i));
+            wu[i] = cmake(fa_uniform(w.x), fa_uniform(w.y));
+        }
+        wu[0] = cmake(1.0, 0.0);
+        wbase = big_twiddle(G.btw, (unsigned)k1 * (unsigned)FA_TID);
         sc[0] = G.y_unscaled ? level_in_scale(G.L, 2 * P) : 1.0;
         sc[1] = G.y_unscaled ? level_in_scale(G.L, 2 * P + 1) : 1.0;
         // bookkeeping of the level, done once per pair before the column kernel that follows:
@@ -932,7 +941,7 @@ template <int N2, int R> struct MidIO {
     // element (no register array: the row kernel is at its VGPR budget)
     FA_DEV cplx twiddle(cplx base, int i) const
     {
-        return (i == 0) ? base : base * big_twiddle(G.btw, (unsigned)k1 * (unsigned)((N2 / R) * i));
+        return (i == 0) ? base : base * wu[i];
     }
     FA_DEV void load(int which, int e, cplx (&x)[R], int v, int)
     {
@@ -945,7 +954,7 @@ template <int N2, int R> struct MidIO {
         } else {
             src = G.Y + (pi * (size_t)G.N1 + k1) * N2;
         }
-        const cplx base = big_twiddle(G.btw, (unsigned)k1 * (unsigned)v) * sc[which];
+        const cplx base = wbase * sc[which];
 #pragma unroll
         for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i] * twiddle(base, i);
     }
@@ -969,7 +978,7 @@ template <int N2, int R> struct MidIO {
     {
         const int n_out = G.L.n_in / 2;
         cplx *dst = G.Z + ((size_t)((size_t)e * n_out + P) * G.N1 + k1) * N2;
-        const cplx base = big_twiddle(G.btw, (unsigned)k1 * (unsigned)v) * (1.0 / (double)N2);
+        const cplx base = wbase * (1.0 / (double)N2);
 #pragma unroll
         for (int i = 0; i < R; i++) dst[v + (N2 / R) * i] = x[i] * cconj(twiddle(base, i));
     }
