@@ -596,3 +596,49 @@ def test_concurrent_host_threads(capi, oracle):
             assert rc3 == 0 and bs.size == bs_o.size
             for v in bs_o:
                 assert np.min(np.abs(bs - v)) < 1e-9
+
+
+def test_discrete_spectrum_options(capi, oracle, fixtures):
+    """discspec_type (norming constants / residues / both, fnft_nsev.c:946-964), filtering (NONE keeps the
+    spurious roots, BASIC the upper half plane, FULL the bounding box, :615-650) and a bound_states buffer
+    that is too small (:728-734: as many as fit, plus a warning through the printf hook)."""
+    fx = fixtures["nsev_sech_focusing"]
+    D = 1024
+    q = S.sech_focusing(D)
+    T = fx["T"]
+    rc, bs, nc, res = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", dstype="BOTH")
+    assert rc == 0 and bs.size == 3
+    rc, bs1, nc1, res1 = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", dstype="NORMING_CONSTANTS")
+    assert rc == 0 and res1 is None and np.allclose(bs1, bs, atol=1e-13) and np.allclose(nc1, nc, rtol=1e-12)
+    rc, bs2, nc2, res2 = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", dstype="RESIDUES")
+    assert rc == 0 and nc2 is None and np.allclose(res2, res, rtol=1e-12)
+    # filtering: raw roots of the a-polynomial of the (not subsampled) signal
+    rc, bsn, _, _ = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="FAST_EIGENVALUE", bsfilt="NONE",
+                                      dstype="NORMING_CONSTANTS")
+    assert rc == 0 and bsn.size == 2 * D          # every root: deg * D
+    rc, bsb, _, _ = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="FAST_EIGENVALUE", bsfilt="BASIC",
+                                      dstype="NORMING_CONSTANTS")
+    assert rc == 0 and 3 <= bsb.size < 2 * D and np.all(bsb.imag >= 0)
+    rc, bsf, _, _ = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="FAST_EIGENVALUE", bsfilt="FULL",
+                                      dstype="NORMING_CONSTANTS")
+    assert rc == 0 and bsf.size == 3
+    for v in (0.7j, 1.7j, 2.7j):
+        assert np.min(np.abs(bsf - v)) < 1e-3 and np.min(np.abs(bsb - v)) < 1e-3 and np.min(np.abs(bsn - v)) < 1e-3
+    # capacity 2 for 3 bound states
+    import ctypes as C
+    msgs = []
+    CB = C.CFUNCTYPE(C.c_int32, C.c_char_p)
+
+    @CB
+    def hook(fmt):
+        msgs.append(fmt)
+        return 0
+    L = capi.load()
+    old = L.fnft_errwarn_getprintf()
+    L.fnft_errwarn_setprintf(C.cast(hook, C.c_void_p))
+    try:
+        rc, bsk, nck, resk = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", K=2)
+    finally:
+        L.fnft_errwarn_setprintf(old)
+    assert rc == 0 and bsk.size == 2
+    assert any(b"Warning" in m for m in msgs)
