@@ -12,9 +12,11 @@ D = M = 2^20 complex128 samples, q = 3.2i*sech(t), T = [-25, 25], XI = [-7/5, 8/
 `--workload cfg3` runs BASELINE.json configs[2] instead (512 independent signals of D = M = 2^16 over 8
 GPUs = 64 signals per GPU in one batched plan, XI = [-4, 4]); the default is the headline configs[1].
 
-With N ranks every rank transforms its own signal (weak scaling, no data-path collective) and
-the result shards are gathered on rank 0 with one RCCL gather per step, overlapped with the next
-step's compute on RCCL's stream.  Rank 0 prints ONE JSON line.
+With N ranks every rank transforms its own signal (weak scaling, no data-path collective: the signals
+are independent).  The job's ONE RCCL gather collects the result shards of the last step on rank 0
+inside the timed region (`--gather job`, default); `--gather step` gathers after every step
+(overlapped with the next step's compute), `--gather none` leaves the results sharded.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -47,7 +49,11 @@ def main():
                     help="cfg2: one signal D=M=2^20 per GPU (headline); cfg3: BASELINE.json configs[2], "
                          "64 of the 512 signals D=M=2^16 per GPU; cfg5: configs[4], fnft_kdvv D=M=2^18 2SPLIT8B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
+    ap.add_argument("--gather", choices=("job", "step", "none"), default="job",
+                    help="N>1: 'job' = ONE RCCL gather of the result shards per job (after the last of the K "
+                         "steps, inside the timed region); 'step' = a gather after every step, overlapped "
+                         "with the next step; 'none' = results stay sharded")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 control-flow rehearsal on a box with fewer GPUs than ranks: gloo backend, "
                          "host-staged gather, ranks share the visible GPUs (not a measurement)")
@@ -73,6 +79,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.no_gather:
+        args.gather = "none"
     cfg3 = args.workload == "cfg3"
     cfg5 = args.workload == "cfg5"
     if cfg3:
@@ -105,7 +113,7 @@ def main():
     nout = 1 if cfg5 else 3   # fnft_kdvv returns the reflection coefficient only
     outs = [torch.zeros(B * nout * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
     gather_bufs = None
-    if world > 1 and rank == 0 and not args.no_gather:
+    if world > 1 and rank == 0 and args.gather != "none":
         gather_bufs = [[torch.zeros(B * nout * M, 2, dtype=torch.float64,
                                     device="cpu" if args.rehearse_gloo else "cuda") for _ in range(world)]
                        for _ in range(2)]
@@ -117,12 +125,12 @@ def main():
         return plan.contspec_device(dq.data_ptr(), out_ptr, T, XI, kappa=1, contspec_type="BOTH",
                                     normalization_flag=1, stream=stream)
 
-    def one_step(i, pending):
+    def one_step(i, pending, last=False):
         buf = outs[i % 2]
         rc = transform(buf.data_ptr())
         if rc != 0:
             raise RuntimeError("fnft_amd_nsev_contspec_device rc=%d: %s" % (rc, capi.last_error()))
-        if world > 1 and not args.no_gather:
+        if world > 1 and (args.gather == "step" or (args.gather == "job" and last)):
             # the buffer written two steps ago must have been gathered before it is reused
             if len(pending) >= 2:
                 pending.pop(0).wait()
@@ -141,7 +149,7 @@ def main():
 
     pending = []
     for i in range(args.warmup):
-        one_step(i, pending)
+        one_step(i, pending, last=(i == args.warmup - 1))
     for w in pending:
         w.wait()
     pending = []
@@ -155,7 +163,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
-        one_step(i, pending)
+        one_step(i, pending, last=(i == args.steps - 1))
     for w in pending:
         w.wait()
     ev1.record()
@@ -241,7 +249,7 @@ def main():
                                    % ("fnft_kdvv" if cfg5 else "fnft_nsev", args.log2D,
                                       "reflection" if cfg5 else "a,b + reflection", args.disc, B, "" if B == 1 else "s",
                                       " (configs[2]: 512 signals over 8 GPUs)" if cfg3 else ""),
-                       "per_step_gather": bool(world > 1 and not args.no_gather),
+                       "gather": (args.gather if world > 1 else "n/a (1 GPU)"),
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
             "roofline": roof, "cpu_baseline": cpu,
         }
