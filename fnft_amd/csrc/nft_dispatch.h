@@ -280,6 +280,34 @@ template <class BE, int N> void run_pair_fft(BE &be, const TreeLevel &L)
     if (L.ne == 4) be.template run<KPairFft<N, 4>>((pairs + B4 - 1) / B4, 1, L);
     else be.template run<KPairFft<N, 2>>((pairs + B2 - 1) / B2, 1, L);
 }
+// STAGES levels in one launch (symmetric form): T = 256 lanes (512 when the last stage is 4096 long)
+template <int N0, int STAGES> struct MultiCfg {
+    static constexpr int R = 8;
+    static constexpr int NF = N0 << (STAGES - 1);
+    static constexpr int THREADS = (NF >= 4096) ? 512 : 256;
+    static constexpr int BF = THREADS * R / NF;
+    static constexpr int P0 = BF << (STAGES - 1);
+};
+template <int N0, int STAGES> struct KMulti {
+    using Params = TreeLevel;
+    using C = MultiCfg<N0, STAGES>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes()
+    {
+        return ((size_t)C::THREADS * C::R + (size_t)4 * C::P0) * sizeof(cplx) + (size_t)C::BF * sizeof(unsigned long long);
+    }
+    static FA_DEV void body(const Params &p) { body_multi_fft<N0, STAGES, C::R, C::BF>(p); }
+};
+// N: transform length of the first of the `stages` levels
+template <class BE> bool dispatch_multi(BE &be, const TreeLevel &L, int N, int stages)
+{
+#define X(n0, st) if (N == n0 && stages == st) { be.template run<KMulti<n0, st>>((L.n_in + 2 * MultiCfg<n0, st>::P0 - 1) / (2 * MultiCfg<n0, st>::P0), 1, L); return true; }
+    X(16, 3) X(32, 3) X(64, 3) X(128, 3) X(256, 3) X(512, 3) X(1024, 3)
+    X(16, 2) X(32, 2) X(64, 2) X(128, 2) X(256, 2) X(512, 2) X(1024, 2) X(2048, 2)
+#undef X
+    return false;
+}
 template <class BE> void run_mid(BE &be, const BigLevel &G)
 {
     const int g = (G.L.n_in / 2) * G.N1;

@@ -47,6 +47,7 @@ struct TreeLevel {
     int ne;                        // stored entries per matrix: 4 general, 2 symmetric (11, 21)
     int kappa;                     // +1 focusing / -1 defocusing (symmetric form only)
     int dbg;                       // timing ablation (tests/gpu_debug only): 1 skip transforms, 2 skip loads, 4 skip stores
+    const cplx *twm[3];            // multi-level kernel (body_multi_fft): tables for N0, 2*N0, 4*N0
 };
 
 // floor(log2(sqrt(m2))) for m2 > 0 (normal), exactly, from the exponent field
@@ -842,6 +843,234 @@ template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const 
         L.scale_out[io.P] = pow2i(-a);
         L.wexp_out[io.P] = L.wexp_in[2 * io.P] + L.wexp_in[2 * io.P + 1] + a;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2c: STAGES consecutive levels of the tree in one launch (symmetric form, N = 2d).  A workgroup
+// owns 2^STAGES * BF consecutive matrices: stage s multiplies pairs with transforms of length
+// N0*2^s, and the products stay on chip -- they cross to the lanes of the next stage through the
+// transform buffer in LDS (coefficient arrays rotated by the pair index against bank conflicts).
+// Only the first stage reads HBM and only the last one writes it; intermediate products are not
+// rescaled (two or three products of rescaled factors cannot overflow).  T = BF * NF / R lanes,
+// NF = N0 * 2^(STAGES-1).
+// LDS: T*R transform/staging elements, then per stage the tails (2 per product), then BF maxima.
+// ---------------------------------------------------------------------------------------------
+template <int N, int R, int PAIRS> struct MultiStage {
+    // symmetric pair product of the `PAIRS` pairs held by the workgroup; on entry a11.. hold the
+    // factors (natural order, zero padded), on exit c11 / c21 the cyclic products times N
+    static FA_DEV void product(cplx (&a11)[R], cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], cplx *lds, int v,
+                               int c, const cplx *tw, int kappa)
+    {
+        int parity = 0;
+        fft_wg<N, R, PAIRS, -1, false>(a11, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, -1, false>(a21, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, -1, false>(b11, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, -1, false>(b21, lds, v, c, tw, parity);
+        // g[m] = exp(-2 pi i d m/N) = (-1)^m for N = 2d; m = v + (N/R) i has the parity of v (N/R even)
+        const double g = ((N / R) % 2 == 0) ? ((v & 1) ? -1.0 : 1.0) : 0.0;
+        const double mk = (double)(-kappa);
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const double gi = ((N / R) % 2 == 0) ? g : (((v + (N / R) * i) & 1) ? -1.0 : 1.0);
+            const cplx gb = b21[i] * gi;
+            const cplx c11 = cfma(cconj(a21[i]) * mk, gb, a11[i] * b11[i]);
+            const cplx c21 = cfma(cconj(a11[i]), gb, a21[i] * b11[i]);
+            b11[i] = c11;
+            b21[i] = c21;
+        }
+        fft_wg<N, R, PAIRS, +1, false>(b11, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, +1, false>(b21, lds, v, c, tw, parity);
+    }
+};
+
+
+// tail (constant term) of the symmetric product from the factors' constant terms and the left
+// factor's leading coefficients (tail_product_sym), all taken from registers: the lane with v == 0
+// holds element 0 (leading coefficient) in x[0]; the constant terms come from `tA`, `tB`
+FA_DEV cplx multi_tail(int e, cplx tA0, cplx tA1, cplx tB0, cplx tB1, cplx lead0, cplx lead1, int kappa)
+{
+    TailSet t;
+    t.tA[0] = tA0; t.tA[1] = tA1; t.tB[0] = tB0; t.tB[1] = tB1; t.leadA[0] = lead0; t.leadA[1] = lead1;
+    return tail_product_sym(t, e, kappa);
+}
+
+template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
+    static constexpr int N = N0 << S;                      // transform length of this stage
+    static constexpr int PAIRS = BF << (STAGES - 1 - S);   // pairs of this stage
+    static constexpr int T = BF * (N0 << (STAGES - 1)) / R;
+    static constexpr bool last = (S == STAGES - 1);
+
+    static FA_DEV void run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
+                           cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0)
+    {
+        const int tid = FA_TID;
+        const int c = tid % PAIRS, v = tid / PAIRS;
+        constexpr int d = N / 2;                            // degree of the factors of this stage
+        const int n_stage = L.n_in >> S;                    // matrices entering this stage (all signals)
+        const long long pair_g = (mat0 >> (S + 1)) + c;     // global index of the product
+        const bool act = pair_g < (n_stage >> 1);
+        // constant terms of the two factors and leading coefficients of the left one
+        cplx tA0, tA1, tB0, tB1;
+        if (S == 0) {
+            const long long mA = mat0 + 2 * c;
+            const double sA = act ? L.scale_in[mA] : 0.0, sB = act ? L.scale_in[mA + 1] : 0.0;
+            tA0 = act ? L.tail_in[mA] * sA : cmake(0.0, 0.0);
+            tA1 = act ? L.tail_in[(size_t)L.n_in + mA] * sA : cmake(0.0, 0.0);
+            tB0 = act ? L.tail_in[mA + 1] * sB : cmake(0.0, 0.0);
+            tB1 = act ? L.tail_in[(size_t)L.n_in + mA + 1] * sB : cmake(0.0, 0.0);
+        } else {
+            const cplx *tp = tails + (size_t)(S - 1) * 2 * (2 * (BF << (STAGES - 1)) / 2);
+            tA0 = tp[(size_t)(2 * c) * 2]; tA1 = tp[(size_t)(2 * c) * 2 + 1];
+            tB0 = tp[(size_t)(2 * c + 1) * 2]; tB1 = tp[(size_t)(2 * c + 1) * 2 + 1];
+        }
+        const cplx lead0 = a11[0], lead1 = a21[0];          // meaningful in the lanes with v == 0
+        MultiStage<N, R, PAIRS>::product(a11, a21, b11, b21, lds, v, c, L.twm[S], L.kappa);
+        const double inv = 1.0 / (double)N;
+        cplx tp0 = cmake(0.0, 0.0), tp1 = tp0;
+        if (v == 0) {
+            tp0 = multi_tail(0, tA0, tA1, tB0, tB1, lead0, lead1, L.kappa);
+            tp1 = multi_tail(1, tA0, tA1, tB0, tB1, lead0, lead1, L.kappa);
+        }
+        if constexpr (!last) {
+            // hand the products over to the lanes of the next stage: X[pair][(idx + pair) mod N]
+            cplx *tnext = tails + (size_t)S * 2 * (BF << (STAGES - 1));
+            constexpr int PN = PAIRS / 2, NN = 2 * N;          // next stage: pairs, length
+            const int c2 = tid % PN, v2 = tid / PN;
+            cplx na[R], nb[R];
+            for (int e = 0; e < 2; e++) {
+                FA_SYNC();   // the transform buffer is free (previous readers done)
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int idx = v + (N / R) * i;
+                    cplx val = (e == 0 ? b11[i] : b21[i]) * inv;
+                    if (idx == 0) val = val - (e == 0 ? tp0 : tp1);   // un-alias coefficient 2d folded onto 0
+                    const int rot = (idx + c) & (N - 1);
+                    lds[(size_t)c * N + rot] = val;
+                }
+                if (v == 0) tnext[(size_t)c * 2 + e] = (e == 0 ? tp0 : tp1);
+                FA_SYNC();
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int idx = v2 + (NN / R) * i;         // element of the next stage's factor
+                    cplx xa = cmake(0.0, 0.0), xb = xa;
+                    if (idx < N) {
+                        const int ra = (idx + 2 * c2) & (N - 1), rb = (idx + 2 * c2 + 1) & (N - 1);
+                        xa = lds[(size_t)(2 * c2) * N + ra];
+                        xb = lds[(size_t)(2 * c2 + 1) * N + rb];
+                    } else if (idx == N) {
+                        xa = tnext[(size_t)(2 * c2) * 2 + e];
+                        xb = tnext[(size_t)(2 * c2 + 1) * 2 + e];
+                    }
+                    na[i] = xa; nb[i] = xb;
+                }
+                if (e == 0) {
+#pragma unroll
+                    for (int i = 0; i < R; i++) { a11[i] = na[i]; b11[i] = nb[i]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < R; i++) { a21[i] = na[i]; b21[i] = nb[i]; }
+                }
+            }
+            MultiRun<N0, STAGES, R, BF, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0);
+        } else {
+            // ---- last stage: maxima, pending scale, coalesced stores through LDS ------------------
+            const int n_out = n_stage >> 1;
+            double m2 = 0.0;
+            for (int e = 0; e < 2; e++) {
+                FA_SYNC();
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int idx = v + (N / R) * i;
+                    cplx val = (e == 0 ? b11[i] : b21[i]) * inv;
+                    if (idx == 0) {
+                        const cplx tp = (e == 0 ? tp0 : tp1);
+                        val = val - tp;
+                        if (act) {
+                            L.tail_out[(size_t)e * n_out + pair_g] = tp;
+                            m2 = fmax(m2, cnorm2(tp));
+                        }
+                    }
+                    if (act) m2 = fmax(m2, cnorm2(val));
+                    const int rot = (idx + c) & (N - 1);
+                    lds[(size_t)c * N + rot] = val;
+                }
+                FA_SYNC();
+                const long long Pg0 = mat0 >> (S + 1);
+                const long long nvalid = (n_out - Pg0 < PAIRS) ? n_out - Pg0 : PAIRS;
+                const int total = (int)nvalid * N;
+                cplx *out0 = L.body_out + (size_t)e * L.plane + (size_t)Pg0 * N;
+                for (int m = tid; m < total; m += T) {
+                    const int c3 = m / N, i3 = m - c3 * N;
+                    const int rot = (i3 + c3) & (N - 1);
+                    out0[m] = lds[(size_t)c3 * N + rot];
+                }
+            }
+            if (act) fa_atomic_max_u64(&mx[c], dbits(m2));
+            FA_SYNC();
+            if (v == 0 && act) {
+                const double mm = bitsd(mx[c]);
+                int a = 0;
+                if (mm > 0.0 && mm < 1.0e300) a = half_exponent(mm);
+                L.scale_out[pair_g] = pow2i(-a);
+                int w = a;
+                const long long m_first = pair_g << STAGES;      // input matrices of this product
+                for (int j = 0; j < (1 << STAGES); j++) w += L.wexp_in[m_first + j];
+                L.wexp_out[pair_g] = w;
+            }
+        }
+    }
+};
+template <int N0, int STAGES, int R, int BF, int S>
+FA_DEV void multi_stage_run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
+                            cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0)
+{
+    MultiRun<N0, STAGES, R, BF, S>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0);
+}
+
+template <int N0, int STAGES, int R, int BF> FA_DEV void body_multi_fft(const TreeLevel &L)
+{
+    constexpr int NF = N0 << (STAGES - 1);
+    constexpr int T = BF * NF / R;
+    constexpr int P0 = BF << (STAGES - 1);          // pairs of stage 0
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    cplx *tails = lds + (size_t)T * R;              // [stage][pair][2]
+    unsigned long long *mx = (unsigned long long *)(tails + (size_t)2 * 2 * P0);
+    const int tid = FA_TID;
+    const long long blk = FA_BID;
+    const int n_in = L.n_in;
+    const long long mat0 = blk * (2 * P0);          // first input matrix of the workgroup
+    if (tid < BF) mx[tid] = 0ull;
+    cplx a11[R], a21[R], b11[R], b21[R];
+    // ---- stage 0: factors from HBM -----------------------------------------------------------
+    {
+        const int c = tid % P0, v = tid / P0;
+        const long long mA = mat0 + 2 * c, mB = mA + 1;
+        const bool act = mB < n_in;
+        const int d = L.d;
+        const double sA = act ? L.scale_in[mA] : 0.0, sB = act ? L.scale_in[mB] : 0.0;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int idx = v + (N0 / R) * i;
+            cplx x0 = cmake(0.0, 0.0), x1 = x0, y0 = x0, y1 = x0;
+            if (act) {
+                if (idx < d) {
+                    x0 = L.body_in[(size_t)mA * d + idx] * sA;
+                    x1 = L.body_in[L.plane + (size_t)mA * d + idx] * sA;
+                    y0 = L.body_in[(size_t)mB * d + idx] * sB;
+                    y1 = L.body_in[L.plane + (size_t)mB * d + idx] * sB;
+                } else if (idx == d) {
+                    x0 = L.tail_in[mA] * sA;
+                    x1 = L.tail_in[(size_t)n_in + mA] * sA;
+                    y0 = L.tail_in[mB] * sB;
+                    y1 = L.tail_in[(size_t)n_in + mB] * sB;
+                }
+            }
+            a11[i] = x0; a21[i] = x1; b11[i] = y0; b21[i] = y1;
+        }
+    }
+    // ---- stages ---------------------------------------------------------------------------------
+    multi_stage_run<N0, STAGES, R, BF, 0>(L, lds, tails, mx, a11, a21, b11, b21, mat0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -156,6 +156,7 @@ public:
     bool use_bridge = true;  // fuse inverse/forward column steps of consecutive split levels
     bool use_doubling = true; // ... with spectral doubling when N = 2d (body_col_bridge2)
     bool use_sym = true;     // NSE symmetry: store/transform only the first column (ne = 2)
+    bool use_multi = true;   // several consecutive fused levels per launch (body_multi_fft)
     int ne = 4;              // stored entries per matrix in the current tree run
     int kappa_run = 1;
     int dbg_flags = 0;       // timing ablation, set from FNFT_AMD_DBG by the HIP back end (diagnostics only)
@@ -464,6 +465,20 @@ public:
             const size_t N = nft_product_len(d);
             L.tw = (N <= (size_t)kMaxTwTable) ? tw_table(N) : nullptr;
             bool ok;
+            // consecutive fused levels of the symmetric form in one launch: as many as fit (<= 3)
+            int stages = 1;
+            if (use_multi && ne == 2 && d > (size_t)kSchoolMaxDeg && N == 2 * d && N >= 16 && dbg_flags == 0) {
+                while (stages < 3 && (N << stages) <= (size_t)kFusedMaxN && ((n / batch) >> (stages + 1)) >= 1) stages++;
+            }
+            if (stages > 1) {
+                for (int s = 0; s < stages; s++) L.twm[s] = tw_table(N << s);
+                ok = dispatch_multi(be, L, (int)N, stages);
+                if (!ok) return NFT_EC_NOT_YET_IMPLEMENTED;
+                cur ^= 1;
+                n >>= stages;
+                d <<= stages;
+                continue;
+            }
             if (d <= (size_t)kSchoolMaxDeg) {
                 ok = dispatch_pair_school(be, L);
             } else if (N <= (size_t)kFusedMaxN) {
