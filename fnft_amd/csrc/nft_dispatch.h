@@ -295,7 +295,9 @@ template <int N0, int STAGES> struct KMulti {
     static constexpr int MIN_WAVES = 2;
     static constexpr size_t lds_bytes()
     {
-        return ((size_t)C::THREADS * C::R + (size_t)4 * C::P0) * sizeof(cplx) + (size_t)C::BF * sizeof(unsigned long long);
+        constexpr size_t tw = (N0 * ((1 << STAGES) - 1) <= 1024) ? (size_t)N0 * ((1 << STAGES) - 1) : 0;
+        return ((size_t)C::THREADS * C::R + (size_t)4 * C::P0 + tw) * sizeof(cplx)
+               + (size_t)((C::BF + 1) & ~1) * sizeof(unsigned long long);
     }
     static FA_DEV void body(const Params &p) { body_multi_fft<N0, STAGES, C::R, C::BF>(p); }
 };

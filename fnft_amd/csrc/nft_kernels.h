@@ -901,7 +901,7 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
     static constexpr bool last = (S == STAGES - 1);
 
     static FA_DEV void run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
-                           cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0)
+                           cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0, const cplx *const *twp)
     {
         const int tid = FA_TID;
         const int c = tid % PAIRS, v = tid / PAIRS;
@@ -924,7 +924,7 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
             tB0 = tp[(size_t)(2 * c + 1) * 2]; tB1 = tp[(size_t)(2 * c + 1) * 2 + 1];
         }
         const cplx lead0 = a11[0], lead1 = a21[0];          // meaningful in the lanes with v == 0
-        MultiStage<N, R, PAIRS>::product(a11, a21, b11, b21, lds, v, c, L.twm[S], L.kappa);
+        MultiStage<N, R, PAIRS>::product(a11, a21, b11, b21, lds, v, c, twp[S], L.kappa);
         const double inv = 1.0 / (double)N;
         cplx tp0 = cmake(0.0, 0.0), tp1 = tp0;
         if (v == 0) {
@@ -971,7 +971,7 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
                     for (int i = 0; i < R; i++) { a21[i] = na[i]; b21[i] = nb[i]; }
                 }
             }
-            MultiRun<N0, STAGES, R, BF, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0);
+            MultiRun<N0, STAGES, R, BF, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
         } else {
             // ---- last stage: maxima, pending scale, coalesced stores through LDS ------------------
             const int n_out = n_stage >> 1;
@@ -1022,9 +1022,9 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
 };
 template <int N0, int STAGES, int R, int BF, int S>
 FA_DEV void multi_stage_run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
-                            cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0)
+                            cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0, const cplx *const *twp)
 {
-    MultiRun<N0, STAGES, R, BF, S>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0);
+    MultiRun<N0, STAGES, R, BF, S>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
 }
 
 template <int N0, int STAGES, int R, int BF> FA_DEV void body_multi_fft(const TreeLevel &L)
@@ -1041,6 +1041,21 @@ template <int N0, int STAGES, int R, int BF> FA_DEV void body_multi_fft(const Tr
     const int n_in = L.n_in;
     const long long mat0 = blk * (2 * P0);          // first input matrix of the workgroup
     if (tid < BF) mx[tid] = 0ull;
+    // twiddle tables of all stages in LDS when they are small (N0 + 2 N0 + .. <= 1024 entries)
+    constexpr int kTwTotal = N0 * ((1 << STAGES) - 1);
+    constexpr bool kTwLds = kTwTotal <= 1024;
+    const cplx *twp[3] = {L.twm[0], L.twm[1], L.twm[2]};
+    if (kTwLds) {
+        cplx *twl = (cplx *)(mx + ((BF + 1) & ~1));   // 16-byte aligned after the maxima
+        int off = 0;
+        for (int s = 0; s < STAGES; s++) {
+            const int len = N0 << s;
+            for (int j = tid; j < len; j += T) twl[off + j] = L.twm[s][j];
+            twp[s] = twl + off;
+            off += len;
+        }
+        FA_SYNC();
+    }
     cplx a11[R], a21[R], b11[R], b21[R];
     // ---- stage 0: factors from HBM -----------------------------------------------------------
     {
@@ -1070,7 +1085,7 @@ template <int N0, int STAGES, int R, int BF> FA_DEV void body_multi_fft(const Tr
         }
     }
     // ---- stages ---------------------------------------------------------------------------------
-    multi_stage_run<N0, STAGES, R, BF, 0>(L, lds, tails, mx, a11, a21, b11, b21, mat0);
+    multi_stage_run<N0, STAGES, R, BF, 0>(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
 }
 
 // ---------------------------------------------------------------------------------------------
