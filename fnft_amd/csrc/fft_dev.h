@@ -176,7 +176,7 @@ template <int SIGN> struct RegDft<32, SIGN> {
 // elements a permutation of itself, so the lane-contiguous reads stay conflict-free.
 template <int N> FA_HD int lds_swz(int a) { return (N >= 64) ? (a ^ ((a >> 3) & 7)) : a; }
 
-template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S> struct FftPass {
+template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S, bool TWC = false> struct FftPass {
     static constexpr int r = (NCUR < R) ? NCUR : R;
     static constexpr int J = R / r;     // butterflies per lane
     static constexpr int m = NCUR / r;
@@ -197,8 +197,24 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S> struct FftPas
             for (int k = 0; k < r; k++) t[k] = x[j + J * k];
             RegDft<r, SIGN>::run(t);
             if constexpr (!last) {
+                if constexpr (TWC && r == 8) {
+                    // three table reads (w, w^2, w^4), the other powers by multiplication: the tables of
+                    // the long transforms live in L2, and the level kernels have VALU cycles to spare
+                    const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
+                    const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
+                    const cplx w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+                    const cplx w3 = w1 * w2;
+                    t[1] = t[1] * w1;
+                    t[2] = t[2] * w2;
+                    t[3] = t[3] * w3;
+                    t[4] = t[4] * w4;
+                    t[5] = t[5] * (w1 * w4);
+                    t[6] = t[6] * (w2 * w4);
+                    t[7] = t[7] * (w3 * w4);
+                } else {
 #pragma unroll
-                for (int k = 1; k < r; k++) t[k] = t[k] * tw_dir<SIGN>(tw[(size_t)(p * k) * S]);
+                    for (int k = 1; k < r; k++) t[k] = t[k] * tw_dir<SIGN>(tw[(size_t)(p * k) * S]);
+                }
 #pragma unroll
                 for (int k = 0; k < r; k++) buf[(size_t)lds_swz<N>(q + S * (r * p + k)) * B + c] = t[k];
             } else {
@@ -211,20 +227,20 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S> struct FftPas
 #pragma unroll
             for (int i = 0; i < R; i++) x[i] = buf[(size_t)lds_swz<N>(v + (N / R) * i) * B + c];
             parity ^= 1;
-            FftPass<N, R, B, SIGN, DB, NCUR / r, S * r>::run(x, lds, v, c, tw, parity);
+            FftPass<N, R, B, SIGN, DB, NCUR / r, S * r, TWC>::run(x, lds, v, c, tw, parity);
         }
     }
 };
 
-template <int N, int R, int B, int SIGN, bool DB, int S> struct FftPass<N, R, B, SIGN, DB, 1, S> {
+template <int N, int R, int B, int SIGN, bool DB, int S, bool TWC> struct FftPass<N, R, B, SIGN, DB, 1, S, TWC> {
     static FA_DEV void run(cplx (&)[R], cplx *, int, int, const cplx *__restrict__, int &) {}
 };
 
-template <int N, int R, int B, int SIGN, bool DB = true>
+template <int N, int R, int B, int SIGN, bool DB = true, bool TWC = false>
 FA_DEV void fft_wg(cplx (&x)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw, int &parity)
 {
     static_assert(N >= R, "fft_wg: N must be at least R");
-    FftPass<N, R, B, SIGN, DB, N, 1>::run(x, lds, v, c, tw, parity);
+    FftPass<N, R, B, SIGN, DB, N, 1, TWC>::run(x, lds, v, c, tw, parity);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -287,6 +287,12 @@ template <int N0, int STAGES> struct MultiCfg {
     static constexpr int THREADS = (NF >= 4096) ? 512 : 256;
     static constexpr int BF = THREADS * R / NF;
     static constexpr int P0 = BF << (STAGES - 1);
+#ifndef FA_MULTI_DB
+#define FA_MULTI_DB 1
+#endif
+    // double-buffered transform exchange (one barrier per pass): 0 never, 1 for the 512-lane
+    // configuration only, 2 always
+    static constexpr bool DB = (FA_MULTI_DB == 2) || (FA_MULTI_DB == 1 && THREADS == 512);
 };
 template <int N0, int STAGES> struct KMulti {
     using Params = TreeLevel;
@@ -296,10 +302,10 @@ template <int N0, int STAGES> struct KMulti {
     static constexpr size_t lds_bytes()
     {
         constexpr size_t tw = (N0 * ((1 << STAGES) - 1) <= 1024) ? (size_t)N0 * ((1 << STAGES) - 1) : 0;
-        return ((size_t)C::THREADS * C::R + (size_t)4 * C::P0 + tw) * sizeof(cplx)
+        return ((size_t)(C::DB ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw) * sizeof(cplx)
                + (size_t)((C::BF + 1) & ~1) * sizeof(unsigned long long);
     }
-    static FA_DEV void body(const Params &p) { body_multi_fft<N0, STAGES, C::R, C::BF>(p); }
+    static FA_DEV void body(const Params &p) { body_multi_fft<N0, STAGES, C::R, C::BF, C::DB>(p); }
 };
 // N: transform length of the first of the `stages` levels
 template <class BE> bool dispatch_multi(BE &be, const TreeLevel &L, int N, int stages)

@@ -601,7 +601,7 @@ template <int N, int T> FA_DEV cplx *stage_twiddles(cplx *dst, const cplx *__res
     return dst;
 }
 
-template <int N, int R, int B, bool DB, class IO>
+template <int N, int R, int B, bool DB, bool TWC = false, class IO>
 FA_DEV void pair_product_core(IO &io, cplx *lds, const cplx *tw)
 {
     const int tid = FA_TID;
@@ -612,28 +612,28 @@ FA_DEV void pair_product_core(IO &io, cplx *lds, const cplx *tw)
 #pragma unroll
     for (int e = 0; e < 4; e++) io.load(0, e, a[e], v, c);
 #pragma unroll
-    for (int e = 0; e < 4; e++) fft_wg<N, R, B, -1, DB>(a[e], lds, v, c, tw, parity);
+    for (int e = 0; e < 4; e++) fft_wg<N, R, B, -1, DB, TWC>(a[e], lds, v, c, tw, parity);
 #pragma unroll
     for (int col = 0; col < 2; col++) {
         cplx b1[R], b2[R];
         io.load(1, col, b1, v, c);
         io.load(1, 2 + col, b2, v, c);
-        fft_wg<N, R, B, -1, DB>(b1, lds, v, c, tw, parity);
-        fft_wg<N, R, B, -1, DB>(b2, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB, TWC>(b1, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB, TWC>(b2, lds, v, c, tw, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const cplx x1 = b1[i], x2 = b2[i];
             b1[i] = cfma(a[1][i], x2, a[0][i] * x1);
             b2[i] = cfma(a[3][i], x2, a[2][i] * x1);
         }
-        fft_wg<N, R, B, +1, DB>(b1, lds, v, c, tw, parity);
+        fft_wg<N, R, B, +1, DB, TWC>(b1, lds, v, c, tw, parity);
         io.store(col, b1, v, c, lds, parity);
-        fft_wg<N, R, B, +1, DB>(b2, lds, v, c, tw, parity);
+        fft_wg<N, R, B, +1, DB, TWC>(b2, lds, v, c, tw, parity);
         io.store(2 + col, b2, v, c, lds, parity);
     }
 }
 
-template <int N, int R, int B, bool DB, class IO>
+template <int N, int R, int B, bool DB, bool TWC = false, class IO>
 FA_DEV void pair_product_core_sym(IO &io, cplx *lds, const cplx *tw, int kappa)
 {
     const int tid = FA_TID;
@@ -652,10 +652,10 @@ FA_DEV void pair_product_core_sym(IO &io, cplx *lds, const cplx *tw, int kappa)
         for (int i = 0; i < R; i++) a11[i] = a21[i] = b11[i] = b21[i] = cmake(1.0 + v, 0.5 * i);
     }
     if (!(dbg & 1)) {
-        fft_wg<N, R, B, -1, DB>(a11, lds, v, c, tw, parity);
-        fft_wg<N, R, B, -1, DB>(a21, lds, v, c, tw, parity);
-        fft_wg<N, R, B, -1, DB>(b11, lds, v, c, tw, parity);
-        fft_wg<N, R, B, -1, DB>(b21, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB, TWC>(a11, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB, TWC>(a21, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB, TWC>(b11, lds, v, c, tw, parity);
+        fft_wg<N, R, B, -1, DB, TWC>(b21, lds, v, c, tw, parity);
     }
     const double mk = (double)(-kappa);
 #pragma unroll
@@ -667,9 +667,9 @@ FA_DEV void pair_product_core_sym(IO &io, cplx *lds, const cplx *tw, int kappa)
         b11[i] = c11;
         b21[i] = c21;
     }
-    if (!(dbg & 1)) fft_wg<N, R, B, +1, DB>(b11, lds, v, c, tw, parity);
+    if (!(dbg & 1)) fft_wg<N, R, B, +1, DB, TWC>(b11, lds, v, c, tw, parity);
     if (!(dbg & 4)) io.store(0, b11, v, c, lds, parity);
-    if (!(dbg & 1)) fft_wg<N, R, B, +1, DB>(b21, lds, v, c, tw, parity);
+    if (!(dbg & 1)) fft_wg<N, R, B, +1, DB, TWC>(b21, lds, v, c, tw, parity);
     if (!(dbg & 4)) io.store(1, b21, v, c, lds, parity);
     if (dbg & 4) io.sink(b11, b21);
 }
@@ -826,8 +826,9 @@ template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const 
     const cplx *tw = L.tw;
     if (kTwLds) tw = stage_twiddles<N, B *(N / R)>(twl, L.tw);
     TreeIO<N, R, B, NE> io(L, c);
-    if (NE == 4) pair_product_core<N, R, B, DB>(io, lds, tw);
-    else pair_product_core_sym<N, R, B, DB>(io, lds, tw, L.kappa);
+    // tables left in L2 (N = 1024, 2048) are read sparingly
+    if (NE == 4) pair_product_core<N, R, B, DB, (N > R) && !kTwLds>(io, lds, tw);
+    else pair_product_core_sym<N, R, B, DB, (N > R) && !kTwLds>(io, lds, tw, L.kappa);
     // every lane's first fft_wg exchange has passed a barrier after mx was zeroed when N > R;
     // for N == R (single pass, no barrier) the group is one lane, so order is trivial.
     if (N > R) {
@@ -855,17 +856,16 @@ template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const 
 // NF = N0 * 2^(STAGES-1).
 // LDS: T*R transform/staging elements, then per stage the tails (2 per product), then BF maxima.
 // ---------------------------------------------------------------------------------------------
-template <int N, int R, int PAIRS> struct MultiStage {
+template <int N, int R, int PAIRS, bool DB, bool TWC> struct MultiStage {
     // symmetric pair product of the `PAIRS` pairs held by the workgroup; on entry a11.. hold the
     // factors (natural order, zero padded), on exit c11 / c21 the cyclic products times N
     static FA_DEV void product(cplx (&a11)[R], cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], cplx *lds, int v,
-                               int c, const cplx *tw, int kappa)
+                               int c, const cplx *tw, int kappa, int &parity)
     {
-        int parity = 0;
-        fft_wg<N, R, PAIRS, -1, false>(a11, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, -1, false>(a21, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, -1, false>(b11, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, -1, false>(b21, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, -1, DB, TWC>(a11, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, -1, DB, TWC>(a21, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, -1, DB, TWC>(b11, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, -1, DB, TWC>(b21, lds, v, c, tw, parity);
         // g[m] = exp(-2 pi i d m/N) = (-1)^m for N = 2d; m = v + (N/R) i has the parity of v (N/R even)
         const double g = ((N / R) % 2 == 0) ? ((v & 1) ? -1.0 : 1.0) : 0.0;
         const double mk = (double)(-kappa);
@@ -878,8 +878,8 @@ template <int N, int R, int PAIRS> struct MultiStage {
             b11[i] = c11;
             b21[i] = c21;
         }
-        fft_wg<N, R, PAIRS, +1, false>(b11, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, +1, false>(b21, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, +1, DB, TWC>(b11, lds, v, c, tw, parity);
+        fft_wg<N, R, PAIRS, +1, DB, TWC>(b21, lds, v, c, tw, parity);
     }
 };
 
@@ -894,18 +894,20 @@ FA_DEV cplx multi_tail(int e, cplx tA0, cplx tA1, cplx tB0, cplx tB1, cplx lead0
     return tail_product_sym(t, e, kappa);
 }
 
-template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
+template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
     static constexpr int N = N0 << S;                      // transform length of this stage
     static constexpr int PAIRS = BF << (STAGES - 1 - S);   // pairs of this stage
     static constexpr int T = BF * (N0 << (STAGES - 1)) / R;
     static constexpr bool last = (S == STAGES - 1);
 
     static FA_DEV void run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
-                           cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0, const cplx *const *twp)
+                           cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0, const cplx *const *twp,
+                           int &parity)
     {
         const int tid = FA_TID;
         const int c = tid % PAIRS, v = tid / PAIRS;
         constexpr int d = N / 2;                            // degree of the factors of this stage
+        constexpr size_t kBufElems = (size_t)T * R;         // one transform buffer
         const int n_stage = L.n_in >> S;                    // matrices entering this stage (all signals)
         const long long pair_g = (mat0 >> (S + 1)) + c;     // global index of the product
         const bool act = pair_g < (n_stage >> 1);
@@ -924,7 +926,9 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
             tB0 = tp[(size_t)(2 * c + 1) * 2]; tB1 = tp[(size_t)(2 * c + 1) * 2 + 1];
         }
         const cplx lead0 = a11[0], lead1 = a21[0];          // meaningful in the lanes with v == 0
-        MultiStage<N, R, PAIRS>::product(a11, a21, b11, b21, lds, v, c, twp[S], L.kappa);
+        // tables that did not fit into LDS are read sparingly (three entries per butterfly)
+        MultiStage<N, R, PAIRS, DB, (N0 * ((1 << STAGES) - 1) > 1024)>::product(a11, a21, b11, b21, lds, v, c, twp[S],
+                                                                                L.kappa, parity);
         const double inv = 1.0 / (double)N;
         cplx tp0 = cmake(0.0, 0.0), tp1 = tp0;
         if (v == 0) {
@@ -938,14 +942,17 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
             const int c2 = tid % PN, v2 = tid / PN;
             cplx na[R], nb[R];
             for (int e = 0; e < 2; e++) {
-                FA_SYNC();   // the transform buffer is free (previous readers done)
+                // single buffer: wait until the last exchange has been read; double buffer: the idle
+                // one is free by the hand-over rule of fft_wg
+                cplx *stg = DB ? lds + (size_t)parity * kBufElems : lds;
+                if (!DB) FA_SYNC();
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int idx = v + (N / R) * i;
                     cplx val = (e == 0 ? b11[i] : b21[i]) * inv;
                     if (idx == 0) val = val - (e == 0 ? tp0 : tp1);   // un-alias coefficient 2d folded onto 0
                     const int rot = (idx + c) & (N - 1);
-                    lds[(size_t)c * N + rot] = val;
+                    stg[(size_t)c * N + rot] = val;
                 }
                 if (v == 0) tnext[(size_t)c * 2 + e] = (e == 0 ? tp0 : tp1);
                 FA_SYNC();
@@ -955,8 +962,8 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
                     cplx xa = cmake(0.0, 0.0), xb = xa;
                     if (idx < N) {
                         const int ra = (idx + 2 * c2) & (N - 1), rb = (idx + 2 * c2 + 1) & (N - 1);
-                        xa = lds[(size_t)(2 * c2) * N + ra];
-                        xb = lds[(size_t)(2 * c2 + 1) * N + rb];
+                        xa = stg[(size_t)(2 * c2) * N + ra];
+                        xb = stg[(size_t)(2 * c2 + 1) * N + rb];
                     } else if (idx == N) {
                         xa = tnext[(size_t)(2 * c2) * 2 + e];
                         xb = tnext[(size_t)(2 * c2 + 1) * 2 + e];
@@ -970,14 +977,16 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
 #pragma unroll
                     for (int i = 0; i < R; i++) { a21[i] = na[i]; b21[i] = nb[i]; }
                 }
+                if (DB) parity ^= 1;
             }
-            MultiRun<N0, STAGES, R, BF, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
+            MultiRun<N0, STAGES, R, BF, DB, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity);
         } else {
             // ---- last stage: maxima, pending scale, coalesced stores through LDS ------------------
             const int n_out = n_stage >> 1;
             double m2 = 0.0;
             for (int e = 0; e < 2; e++) {
-                FA_SYNC();
+                cplx *stg = DB ? lds + (size_t)parity * kBufElems : lds;
+                if (!DB) FA_SYNC();
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int idx = v + (N / R) * i;
@@ -992,7 +1001,7 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
                     }
                     if (act) m2 = fmax(m2, cnorm2(val));
                     const int rot = (idx + c) & (N - 1);
-                    lds[(size_t)c * N + rot] = val;
+                    stg[(size_t)c * N + rot] = val;
                 }
                 FA_SYNC();
                 const long long Pg0 = mat0 >> (S + 1);
@@ -1002,8 +1011,9 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
                 for (int m = tid; m < total; m += T) {
                     const int c3 = m / N, i3 = m - c3 * N;
                     const int rot = (i3 + c3) & (N - 1);
-                    out0[m] = lds[(size_t)c3 * N + rot];
+                    out0[m] = stg[(size_t)c3 * N + rot];
                 }
+                if (DB) parity ^= 1;
             }
             if (act) fa_atomic_max_u64(&mx[c], dbits(m2));
             FA_SYNC();
@@ -1020,21 +1030,22 @@ template <int N0, int STAGES, int R, int BF, int S> struct MultiRun {
         }
     }
 };
-template <int N0, int STAGES, int R, int BF, int S>
+template <int N0, int STAGES, int R, int BF, bool DB, int S>
 FA_DEV void multi_stage_run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
                             cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0, const cplx *const *twp)
 {
-    MultiRun<N0, STAGES, R, BF, S>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
+    int parity = 0;
+    MultiRun<N0, STAGES, R, BF, DB, S>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity);
 }
 
-template <int N0, int STAGES, int R, int BF> FA_DEV void body_multi_fft(const TreeLevel &L)
+template <int N0, int STAGES, int R, int BF, bool DB> FA_DEV void body_multi_fft(const TreeLevel &L)
 {
     constexpr int NF = N0 << (STAGES - 1);
     constexpr int T = BF * NF / R;
     constexpr int P0 = BF << (STAGES - 1);          // pairs of stage 0
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
-    cplx *tails = lds + (size_t)T * R;              // [stage][pair][2]
+    cplx *tails = lds + (size_t)(DB ? 2 : 1) * T * R;   // [stage][pair][2]
     unsigned long long *mx = (unsigned long long *)(tails + (size_t)2 * 2 * P0);
     const int tid = FA_TID;
     const long long blk = FA_BID;
@@ -1085,7 +1096,7 @@ template <int N0, int STAGES, int R, int BF> FA_DEV void body_multi_fft(const Tr
         }
     }
     // ---- stages ---------------------------------------------------------------------------------
-    multi_stage_run<N0, STAGES, R, BF, 0>(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
+    multi_stage_run<N0, STAGES, R, BF, DB, 0>(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1234,8 +1245,9 @@ template <int N2, int R, int NE> FA_DEV void body_mid(const BigLevel &G)
     cplx *lds = (cplx *)FA_LDS_PTR;
     MidIO<N2, R> io(G);
     const cplx *tw = G.tw2;
-    if (NE == 4) pair_product_core<N2, R, 1, true>(io, lds, tw);
-    else pair_product_core_sym<N2, R, 1, true>(io, lds, tw, G.L.kappa);
+    // the 2048-entry table stays in L2: three reads per butterfly, other powers by multiplication
+    if (NE == 4) pair_product_core<N2, R, 1, true, true>(io, lds, tw);
+    else pair_product_core_sym<N2, R, 1, true, true>(io, lds, tw, G.L.kappa);
 }
 
 // column step of the inverse transform of every output polynomial
@@ -1727,7 +1739,7 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
         const cplx *vs = C.Vbuf + (size_t)k1 * N2;
 #pragma unroll
         for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i] * tw[i];
-        fft_wg<N2, R, 1, -1, DB>(vv, lds, v, 0, C.tw2, parity);
+        fft_wg<N2, R, 1, -1, DB, true>(vv, lds, v, 0, C.tw2, parity);
         if (C.v_mode == 1 && FA_BID_Y == 0) {
             cplx *vd = C.VS + (size_t)k1 * N2;
 #pragma unroll
@@ -1743,10 +1755,10 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
         cplx y[R];
 #pragma unroll
         for (int i = 0; i < R; i++) y[i] = ys[v + (N2 / R) * i] * tw[i];
-        fft_wg<N2, R, 1, -1, DB>(y, lds, v, 0, C.tw2, parity);
+        fft_wg<N2, R, 1, -1, DB, true>(y, lds, v, 0, C.tw2, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) y[i] = y[i] * vv[i];
-        fft_wg<N2, R, 1, +1, DB>(y, lds, v, 0, C.tw2, parity);
+        fft_wg<N2, R, 1, +1, DB, true>(y, lds, v, 0, C.tw2, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) ys[v + (N2 / R) * i] = (y[i] * inv) * cconj(tw[i]);
     }
