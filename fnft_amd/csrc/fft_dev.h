@@ -211,6 +211,17 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S, bool TWC = fa
                     t[5] = t[5] * (w1 * w4);
                     t[6] = t[6] * (w2 * w4);
                     t[7] = t[7] * (w3 * w4);
+                } else if constexpr (TWC && r == 16) {
+                    const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
+                    const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
+                    const cplx w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+                    const cplx w8 = tw_dir<SIGN>(tw[(size_t)(8 * p) * S]);
+                    const cplx w3 = w1 * w2, w5 = w1 * w4, w6 = w2 * w4, w7 = w3 * w4;
+                    t[1] = t[1] * w1;  t[2] = t[2] * w2;  t[3] = t[3] * w3;  t[4] = t[4] * w4;
+                    t[5] = t[5] * w5;  t[6] = t[6] * w6;  t[7] = t[7] * w7;  t[8] = t[8] * w8;
+                    t[9] = t[9] * (w1 * w8);   t[10] = t[10] * (w2 * w8);  t[11] = t[11] * (w3 * w8);
+                    t[12] = t[12] * (w4 * w8); t[13] = t[13] * (w5 * w8);  t[14] = t[14] * (w6 * w8);
+                    t[15] = t[15] * (w7 * w8);
                 } else {
 #pragma unroll
                     for (int k = 1; k < r; k++) t[k] = t[k] * tw_dir<SIGN>(tw[(size_t)(p * k) * S]);

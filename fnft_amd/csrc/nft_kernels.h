@@ -1150,7 +1150,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLeve
         x[i] = val;
     }
     int parity = 0;
-    fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, G.tw1, parity);
+    fft_wg<N1, R, BC, -1, DB, true>(x, lds, v, c, G.tw1, parity);
     // the twiddle w_N^{n2 k1} between column and row step is applied by the row kernel, where
     // one set of R factors per lane serves every polynomial of the pair
     cplx *dst = G.Y + (size_t)poly * N1 * N2;
@@ -1274,7 +1274,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
         x[i] = src[(size_t)k1 * N2 + n2];   // conj twiddle already applied by the row kernel
     }
     int parity = 0;
-    fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, G.tw1, parity);
+    fft_wg<N1, R, BC, +1, DB, true>(x, lds, v, c, G.tw1, parity);
     cplx *dst = L.body_out + (size_t)e * L.plane + (size_t)P * d2;
     const double inv = 1.0 / (double)N1;
     double m2 = 0.0;
@@ -1350,7 +1350,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
         cplx lo[R];
 #pragma unroll
         for (int i = 0; i < R; i++) lo[i] = x[i];
-        fft_wg<N1, R, BC, +1, DB>(lo, lds, v, c, G.tw1, parity);
+        fft_wg<N1, R, BC, +1, DB, true>(lo, lds, v, c, G.tw1, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) x[i] = lo[i];
     }
@@ -1435,7 +1435,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
 #pragma unroll
     for (int i = 0; i < R; i++) x[i] = src[(size_t)(v + (N1 / R) * i) * N2 + n2];
     int parity = 0;
-    fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, G.tw1, parity);
+    fft_wg<N1, R, BC, +1, DB, true>(x, lds, v, c, G.tw1, parity);
     const double inv = 1.0 / (double)N1;
     double m2 = 0.0;
     cplx tp = cmake(0.0, 0.0);
@@ -1473,7 +1473,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
         x[i] = val * G.tw1x2[n1];   // * w_{2N1}^{n1}
     }
     fa_wave_atomic_max_f64bits(&L.max2_out[P], m2);   // P is uniform in the workgroup
-    fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, G.tw1, parity);
+    fft_wg<N1, R, BC, -1, DB, true>(x, lds, v, c, G.tw1, parity);
     cplx *dst = G.Y + (size_t)poly * N1 * N2;   // odd rows only: [poly][j][n2]
     // column 0: the tail at index N contributes t * w_{2N1}^{N1 (2j+1)} = -t to every odd row
     const bool col0 = (n2 == 0);
@@ -1704,7 +1704,7 @@ template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_f
         x[i] = val;
     }
     int parity = 0;
-    fft_wg<N1, R, BC, -1, DB>(x, lds, v, c, C.tw1, parity);
+    fft_wg<N1, R, BC, -1, DB, true>(x, lds, v, c, C.tw1, parity);
     // the twiddle w_L^{n2 k1} is applied by the row kernel (shared by all rows of one k1)
     cplx *dst = (job < njobs) ? C.Ybuf + (size_t)job * Lc : C.Vbuf;
 #pragma unroll
@@ -1792,7 +1792,7 @@ template <int N1, int R, int BC, bool DB, bool DFT, bool KDV> FA_DEV void body_c
             const int k1 = v + (N1 / R) * i;
             x[i] = src[(size_t)k1 * C.N2 + n2];   // conj twiddle applied by the row kernel
         }
-        fft_wg<N1, R, BC, +1, DB>(x, lds, v, c, C.tw1, parity);
+        fft_wg<N1, R, BC, +1, DB, true>(x, lds, v, c, C.tw1, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const int n1 = v + (N1 / R) * i;
