@@ -142,7 +142,10 @@ template <int N1> struct ColCfg {
     // N1 <= 16: one lane per column, no LDS.  Larger: 16 points per lane so that a tile is
     // BC >= 8 columns wide (global rows of >= 128 bytes), one LDS buffer (two barriers/exchange).
     static constexpr int R = (N1 <= 16) ? N1 : 16;
-    static constexpr int THREADS = (N1 <= 256) ? 256 : 512;
+#ifndef FA_COL_T
+#define FA_COL_T 256
+#endif
+    static constexpr int THREADS = (N1 <= 16) ? 256 : ((N1 <= 256) ? FA_COL_T : 512);
     static constexpr int BC = THREADS / (N1 / R);
     static constexpr bool DB = false;
     static constexpr size_t lds_bytes()
