@@ -310,6 +310,29 @@ template <int N0, int STAGES> struct KMulti {
     }
     static FA_DEV void body(const Params &p) { body_multi_fft<N0, STAGES, C::R, C::BF, C::DB>(p); }
 };
+// leaf + first multi-level launch (N0 = 2*DEG*SPT = 16 for the three leaf configurations with d = 8)
+template <int DEG, int STAGES> struct KLeafMulti {
+    using Params = LeafMultiParams;
+    static constexpr int SPT = LeafCfg<DEG>::SPT;
+    using C = MultiCfg<2 * DEG * SPT, STAGES>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes()
+    {
+        constexpr size_t tw = (size_t)(2 * DEG * SPT) * ((1 << STAGES) - 1);
+        return ((size_t)(C::DB ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw + (size_t)2 * C::THREADS) * sizeof(cplx)
+               + (size_t)((C::BF + 1) & ~1) * sizeof(unsigned long long) + (size_t)C::THREADS * sizeof(int);
+    }
+    static FA_DEV void body(const Params &p) { body_leaf_multi<DEG, SPT, STAGES, C::R, C::BF, C::DB>(p); }
+};
+template <class BE> bool dispatch_leaf_multi(BE &be, const LeafMultiParams &Q, int stages)
+{
+    const int deg = Q.lp.c.deg;
+#define X(dg, st) if (deg == dg && stages == st && 2 * dg * LeafCfg<dg>::SPT == 16) { be.template run<KLeafMulti<dg, st>>((Q.L.n_in + MultiCfg<16, st>::THREADS - 1) / MultiCfg<16, st>::THREADS, 1, Q); return true; }
+    X(1, 3) X(2, 3) X(4, 3) X(1, 2) X(2, 2) X(4, 2)
+#undef X
+    return false;
+}
 // N: transform length of the first of the `stages` levels
 template <class BE> bool dispatch_multi(BE &be, const TreeLevel &L, int N, int stages)
 {

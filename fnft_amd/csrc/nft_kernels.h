@@ -902,7 +902,7 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
 
     static FA_DEV void run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
                            cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0, const cplx *const *twp,
-                           int &parity)
+                           int &parity, const cplx *ltail = nullptr, const int *lwexp = nullptr)
     {
         const int tid = FA_TID;
         const int c = tid % PAIRS, v = tid / PAIRS;
@@ -913,7 +913,11 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
         const bool act = pair_g < (n_stage >> 1);
         // constant terms of the two factors and leading coefficients of the left one
         cplx tA0, tA1, tB0, tB1;
-        if (S == 0) {
+        if (S == 0 && ltail != nullptr) {
+            // leaf fused in front: constant terms of the (already rescaled) factors sit in LDS
+            tA0 = ltail[(size_t)(2 * c) * 2]; tA1 = ltail[(size_t)(2 * c) * 2 + 1];
+            tB0 = ltail[(size_t)(2 * c + 1) * 2]; tB1 = ltail[(size_t)(2 * c + 1) * 2 + 1];
+        } else if (S == 0) {
             const long long mA = mat0 + 2 * c;
             const double sA = act ? L.scale_in[mA] : 0.0, sB = act ? L.scale_in[mA + 1] : 0.0;
             tA0 = act ? L.tail_in[mA] * sA : cmake(0.0, 0.0);
@@ -979,7 +983,8 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
                 }
                 if (DB) parity ^= 1;
             }
-            MultiRun<N0, STAGES, R, BF, DB, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity);
+            MultiRun<N0, STAGES, R, BF, DB, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity, ltail,
+                                                        lwexp);
         } else {
             // ---- last stage: maxima, pending scale, coalesced stores through LDS ------------------
             const int n_out = n_stage >> 1;
@@ -1024,7 +1029,8 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
                 L.scale_out[pair_g] = pow2i(-a);
                 int w = a;
                 const long long m_first = pair_g << STAGES;      // input matrices of this product
-                for (int j = 0; j < (1 << STAGES); j++) w += L.wexp_in[m_first + j];
+                for (int j = 0; j < (1 << STAGES); j++)
+                    w += lwexp ? lwexp[(m_first - mat0) + j] : L.wexp_in[m_first + j];
                 L.wexp_out[pair_g] = w;
             }
         }
@@ -1097,6 +1103,121 @@ template <int N0, int STAGES, int R, int BF, bool DB> FA_DEV void body_multi_fft
     }
     // ---- stages ---------------------------------------------------------------------------------
     multi_stage_run<N0, STAGES, R, BF, DB, 0>(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
+}
+
+// Leaf kernel and the first multi-level launch in one: lane t of the workgroup forms matrix t of the
+// block from SPT samples in registers (body_leaf), the 2*P0 = T matrices cross to the stage-0 lanes
+// (pair t/2, element v + 2 i) through the transform buffer, and STAGES levels follow on chip.
+struct LeafMultiParams {
+    LeafParams lp;
+    TreeLevel L;      // n_in = matrices the leaf produces, d = DEG*SPT; *_in are unused
+};
+template <int DEG, int SPT, int STAGES, int R, int BF, bool DB> FA_DEV void body_leaf_multi(const LeafMultiParams &Q)
+{
+    constexpr int d = DEG * SPT;
+    constexpr int N0 = 2 * d;
+    static_assert(N0 / R == 2, "one lane per matrix: N0/R must be 2");
+    constexpr int NF = N0 << (STAGES - 1);
+    constexpr int T = BF * NF / R;
+    constexpr int P0 = BF << (STAGES - 1);
+    static_assert(T == 2 * P0, "lanes = matrices of the block");
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    cplx *tails = lds + (size_t)(DB ? 2 : 1) * T * R;
+    unsigned long long *mx = (unsigned long long *)(tails + (size_t)2 * 2 * P0);
+    cplx *twl = (cplx *)(mx + ((BF + 1) & ~1));
+    constexpr int kTwTotal = N0 * ((1 << STAGES) - 1);
+    cplx *ltail = twl + kTwTotal;                   // [T][2]
+    int *lwexp = (int *)(ltail + (size_t)2 * T);   // [T]
+    const CoeffParams &P = Q.lp.c;
+    const TreeLevel &L = Q.L;
+    const int tid = FA_TID;
+    const long long mat0 = (long long)FA_BID * T;
+    if (tid < BF) mx[tid] = 0ull;
+    const cplx *twp[3] = {L.twm[0], L.twm[1], L.twm[2]};
+    {
+        int off = 0;
+        for (int s = 0; s < STAGES; s++) {
+            const int len = N0 << s;
+            for (int j = tid; j < len; j += T) twl[off + j] = L.twm[s][j];
+            twp[s] = twl + off;
+            off += len;
+        }
+    }
+    // ---- leaf: matrix mat0 + tid ----------------------------------------------------------------
+    const long long gid = mat0 + tid;
+    const long long per = P.Dpad / SPT;
+    const long long n_out = (long long)P.batch * per;
+    const bool active = gid < n_out;
+    cplx acc[4][d + 1];
+    double sc = 0.0;
+    int aexp = 0;
+    if (active) {
+        const int b = (int)(gid / per);
+        const long long j0 = (gid % per) * SPT;
+        bool ok = true;
+        {
+            CoefMat<DEG> m;
+            ok = leaf_sample<DEG>(P, b, j0, m);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int k2 = 0; k2 <= DEG; k2++) acc[e][k2] = m.p[e][k2];
+        }
+        LeafLoop<DEG, SPT, 1>::run(P, b, j0, acc, ok);
+        if (!ok) fa_atomic_or_i32(P.status, 1);
+        double m2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int k2 = 0; k2 <= d; k2++) m2 = fmax(m2, cnorm2(acc[e][k2]));
+        sc = 1.0;
+        if (m2 > 0.0 && m2 < 1.0e300) {
+            aexp = half_exponent(m2);
+            sc = pow2i(-aexp);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int k2 = 0; k2 <= d; k2++) acc[e][k2] = cmake(0.0, 0.0);
+    }
+    lwexp[tid] = aexp;
+    ltail[(size_t)tid * 2] = acc[0][d] * sc;
+    ltail[(size_t)tid * 2 + 1] = acc[2][d] * sc;
+    // ---- hand-over: bodies of entry 11, then 21, through the transform buffer ---------------------
+    cplx a11[R], a21[R], b11[R], b21[R];
+    const int c = tid % P0, v = tid / P0;     // stage-0 lane: pair c, elements v + 2 i
+    for (int e = 0; e < 2; e++) {
+        FA_SYNC();
+#pragma unroll
+        for (int k2 = 0; k2 < d; k2++) lds[(size_t)tid * d + ((k2 + tid) & (d - 1))] = acc[2 * e][k2] * sc;
+        FA_SYNC();
+        cplx xa[R], xb[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int idx = v + 2 * i;
+            cplx ya = cmake(0.0, 0.0), yb = ya;
+            if (idx < d) {
+                ya = lds[(size_t)(2 * c) * d + ((idx + 2 * c) & (d - 1))];
+                yb = lds[(size_t)(2 * c + 1) * d + ((idx + 2 * c + 1) & (d - 1))];
+            } else if (idx == d) {
+                ya = ltail[(size_t)(2 * c) * 2 + e];
+                yb = ltail[(size_t)(2 * c + 1) * 2 + e];
+            }
+            xa[i] = ya; xb[i] = yb;
+        }
+        if (e == 0) {
+#pragma unroll
+            for (int i = 0; i < R; i++) { a11[i] = xa[i]; b11[i] = xb[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; i++) { a21[i] = xa[i]; b21[i] = xb[i]; }
+        }
+    }
+    FA_SYNC();   // staging fully read before the first transform writes the buffer (DB: buffer 0)
+    int parity = 0;
+    MultiRun<N0, STAGES, R, BF, DB, 0>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity, ltail, lwexp);
 }
 
 // ---------------------------------------------------------------------------------------------

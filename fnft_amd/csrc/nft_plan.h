@@ -157,6 +157,9 @@ public:
     bool use_doubling = true; // ... with spectral doubling when N = 2d (body_col_bridge2)
     bool use_sym = true;     // NSE symmetry: store/transform only the first column (ne = 2)
     bool use_multi = true;   // several consecutive fused levels per launch (body_multi_fft)
+    bool use_leaf_multi = true;   // ... with the leaf kernel in front of the first of them (body_leaf_multi)
+    bool leaf_pending = false;    // run_coeffs left the leaf to the first launch of run_tree
+    LeafParams leaf_lp;
     int ne = 4;              // stored entries per matrix in the current tree run
     int kappa_run = 1;
     int dbg_flags = 0;       // timing ablation, set from FNFT_AMD_DBG by the HIP back end (diagnostics only)
@@ -378,13 +381,20 @@ public:
         // direct-product levels, which the leaf kernel guarantees
         ne = (use_sym && leaf && d_r == nullptr && (size_t)deg0 * spt > (size_t)kSchoolMaxDeg) ? 2 : 4;
         p.ne = ne;
+        leaf_pending = false;
         if (leaf) {
             LeafParams lp;
             lp.c = p;
             lp.spt = spt;
-            if (!dispatch_leaf(be, lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
             start_n = n0 / (size_t)spt;
             start_d = (size_t)deg0 * (size_t)spt;
+            // symmetric form with d = 8: the leaf is computed inside the first multi-level launch
+            if (use_leaf_multi && use_multi && ne == 2 && start_d == 8 && dbg_flags == 0 && start_n / batch >= 4) {
+                leaf_lp = lp;
+                leaf_pending = true;
+                return NFT_SUCCESS;
+            }
+            if (!dispatch_leaf(be, lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
             return NFT_SUCCESS;
         }
         if (prog_ptr != nullptr) {
@@ -470,9 +480,25 @@ public:
             if (use_multi && ne == 2 && d > (size_t)kSchoolMaxDeg && N == 2 * d && N >= 16 && dbg_flags == 0) {
                 while (stages < 3 && (N << stages) <= (size_t)kFusedMaxN && ((n / batch) >> (stages + 1)) >= 1) stages++;
             }
+            if (leaf_pending && stages < 2) {   // cannot happen (start_n/batch >= 4), but never skip the leaf
+                if (!dispatch_leaf(be, leaf_lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
+                leaf_pending = false;
+            }
             if (stages > 1) {
                 for (int s = 0; s < stages; s++) L.twm[s] = tw_table(N << s);
-                ok = dispatch_multi(be, L, (int)N, stages);
+                if (leaf_pending) {
+                    LeafMultiParams Q;
+                    Q.lp = leaf_lp;
+                    Q.L = L;
+                    ok = dispatch_leaf_multi(be, Q, stages);
+                    leaf_pending = false;
+                    if (!ok) {   // configuration without a fused instantiation: leaf, then the levels
+                        if (!dispatch_leaf(be, leaf_lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
+                        ok = dispatch_multi(be, L, (int)N, stages);
+                    }
+                } else {
+                    ok = dispatch_multi(be, L, (int)N, stages);
+                }
                 if (!ok) return NFT_EC_NOT_YET_IMPLEMENTED;
                 cur ^= 1;
                 n >>= stages;
