@@ -203,14 +203,12 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S, bool TWC = fa
                     const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
                     const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
                     const cplx w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+                    // w^5 = w^4 w etc. applied as two factors: same 11 products, fewer live registers
+                    t[4] = t[4] * w4; t[5] = t[5] * w4; t[6] = t[6] * w4; t[7] = t[7] * w4;
+                    t[1] = t[1] * w1; t[5] = t[5] * w1;
+                    t[2] = t[2] * w2; t[6] = t[6] * w2;
                     const cplx w3 = w1 * w2;
-                    t[1] = t[1] * w1;
-                    t[2] = t[2] * w2;
-                    t[3] = t[3] * w3;
-                    t[4] = t[4] * w4;
-                    t[5] = t[5] * (w1 * w4);
-                    t[6] = t[6] * (w2 * w4);
-                    t[7] = t[7] * (w3 * w4);
+                    t[3] = t[3] * w3; t[7] = t[7] * w3;
                 } else if constexpr (TWC && r == 16) {
                     const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
                     const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
