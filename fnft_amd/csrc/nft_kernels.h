@@ -1243,6 +1243,9 @@ struct BigLevel {
     // rows j, read in place from Zprev
     const cplx *Zprev;
     int y_split;
+    // first split level with N1 = 4 and N = 2d: no column kernel -- the row kernel forms the length-4
+    // column transform itself, Y[k1][n2] = x[n2] + i^(-k1) x[N2 + n2] (+ (-1)^k1 tail at n2 = 0)
+    int y_direct;
 };
 
 // column step of the forward transform of every input polynomial of the level
@@ -1302,8 +1305,8 @@ template <int N2, int R> struct MidIO {
         }
         wu[0] = cmake(1.0, 0.0);
         wbase = big_twiddle(G.btw, (unsigned)k1 * (unsigned)FA_TID);
-        sc[0] = G.y_unscaled ? level_in_scale(G.L, 2 * P) : 1.0;
-        sc[1] = G.y_unscaled ? level_in_scale(G.L, 2 * P + 1) : 1.0;
+        sc[0] = (G.y_unscaled || G.y_direct) ? level_in_scale(G.L, 2 * P) : 1.0;
+        sc[1] = (G.y_unscaled || G.y_direct) ? level_in_scale(G.L, 2 * P + 1) : 1.0;
         // bookkeeping of the level, done once per pair before the column kernel that follows:
         // exponent carried so far (this level's own is added by the consumer / the final
         // finalize) and a clean slot for this level's maximum
@@ -1323,6 +1326,29 @@ template <int N2, int R> struct MidIO {
     {
         const int n_in = G.L.n_in;
         const size_t pi = (size_t)e * n_in + 2 * P + which;
+        if (G.y_direct) {
+            // w_4^{k1} = (-i)^{k1}; element n1 = 2 exists only as the constant term (index 2*N2 = d)
+            const size_t mat = (size_t)(2 * P + which);
+            const cplx *b0 = G.L.body_in + (size_t)e * G.L.plane + mat * (size_t)G.L.d;
+            const cplx tl = G.L.tail_in[(size_t)e * n_in + mat];
+            const cplx base = wbase * sc[which];
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const int n2 = v + (N2 / R) * i;
+                const cplx x0 = b0[n2], x1 = b0[N2 + n2];
+                cplx r1;   // x1 * (-i)^k1
+                switch (k1 & 3) {
+                case 0: r1 = x1; break;
+                case 1: r1 = cmake(x1.y, -x1.x); break;
+                case 2: r1 = cmake(-x1.x, -x1.y); break;
+                default: r1 = cmake(-x1.y, x1.x); break;
+                }
+                cplx y = x0 + r1;
+                if (n2 == 0) y = (k1 & 1) ? y - tl : y + tl;
+                x[i] = y * twiddle(base, i);
+            }
+            return;
+        }
         const cplx *src;
         if (G.y_split) {
             const cplx *half = (k1 & 1) ? G.Y : G.Zprev;

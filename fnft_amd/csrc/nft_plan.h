@@ -157,6 +157,7 @@ public:
     bool use_doubling = true; // ... with spectral doubling when N = 2d (body_col_bridge2)
     bool use_sym = true;     // NSE symmetry: store/transform only the first column (ne = 2)
     bool use_multi = true;   // several consecutive fused levels per launch (body_multi_fft)
+    bool use_direct4 = true; // first split level: row kernel forms the length-4 column transform itself
     bool use_leaf_multi = true;   // ... with the leaf kernel in front of the first of them (body_leaf_multi)
     bool leaf_pending = false;    // run_coeffs left the leaf to the first launch of run_tree
     LeafParams leaf_lp;
@@ -524,8 +525,11 @@ public:
                 G.tw1x2 = tw_table((size_t)2 * G.N1);
                 G.btw2 = big_tw(2 * N);
                 G.y_unscaled = y_from_bridge ? 1 : 0;
+                // first split level: a length-4 column transform of two non-zero rows is done by the row
+                // kernel on the fly (saves the column launch and its 32 + 64 MB)
+                G.y_direct = (use_direct4 && !y_from_bridge && G.N1 == 4 && N == 2 * d && dbg_flags == 0) ? 1 : 0;
                 ok = true;
-                if (!y_from_bridge) ok = dispatch_col_fwd(be, G);
+                if (!y_from_bridge && !G.y_direct) ok = dispatch_col_fwd(be, G);
                 if (ok) run_mid(be, G);
                 // bridge straight into the next level's column step when that level is split too
                 const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= 256
