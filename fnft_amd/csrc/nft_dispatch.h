@@ -387,7 +387,7 @@ template <class BE> bool dispatch_col_inv(BE &be, const BigLevel &G)
     default: return false;
     }
 }
-#define FA_FOR_EACH_BRIDGE_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256)
+#define FA_FOR_EACH_BRIDGE_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512)
 template <class BE> bool dispatch_col_bridge(BE &be, const BigLevel &G)
 {
     const int polys = G.L.ne * (G.L.n_in / 2);
