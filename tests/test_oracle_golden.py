@@ -227,7 +227,8 @@ def test_fnft_nsev_discrete_spectrum_bounds(oracle, fixtures, b):
     Hausdorff distance of the bound states, norming constants, residues against the file's bounds."""
     fx = fixtures["nsev_sech_focusing"]
     ex = [S.l2c(fx[k]) for k in ("bound_states", "normconsts", "residues")]
-    for st in b["stages"][:1] + b["stages"][3:]:    # D and the rescaled/Richardson stages (D+-1 repeat D)
+    # CPU budget: the first call of the file and its Richardson calls; the GPU suite replays all of them
+    for st in b["stages"][:1] + [s for s in b["stages"][3:] if s["richardson"]]:
         rc, bs, nc, res = oracle.fnft_nsev_ds(S.sech_focusing(st["D"]), fx["T"], b["discretization"],
                                               richardson=bool(st["richardson"]))
         assert rc == 0
