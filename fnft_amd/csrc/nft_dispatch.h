@@ -145,7 +145,10 @@ template <int N1> struct ColCfg {
 #define FA_COL_R_BIG 16
 #endif
     // points per lane: the whole column up to 16; 16 (two passes up to 256); knob for the longer ones
-    static constexpr int R = (N1 <= 16) ? N1 : ((N1 >= 512) ? FA_COL_R_BIG : 16);
+#ifndef FA_COL_R_MID
+#define FA_COL_R_MID 16
+#endif
+    static constexpr int R = (N1 <= 16) ? N1 : ((N1 >= 512) ? FA_COL_R_BIG : FA_COL_R_MID);
 #ifndef FA_COL_T
 #define FA_COL_T 256
 #endif
