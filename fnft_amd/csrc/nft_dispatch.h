@@ -239,8 +239,13 @@ struct KChirpRows {
     using Params = ChirpParams;
     static constexpr int R = 8;
     static constexpr int THREADS = kRowChirp / R;
-    static constexpr size_t lds_bytes() { return (size_t)2 * kRowChirp * sizeof(cplx); }
-    static FA_DEV void body(const Params &p) { body_chirp_rows<kRowChirp, R, true>(p); }
+#ifndef FA_CHIRP_ROWS_DB
+#define FA_CHIRP_ROWS_DB 1
+#endif
+    static constexpr bool DB = FA_CHIRP_ROWS_DB != 0;
+    static constexpr int MIN_WAVES = DB ? 2 : 4;
+    static constexpr size_t lds_bytes() { return (size_t)(DB ? 2 : 1) * kRowChirp * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_chirp_rows<kRowChirp, R, DB>(p); }
 };
 
 // ---------------------------------------------------------------------------------------------
