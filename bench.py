@@ -38,6 +38,73 @@ def bytes_tree(D, deg0):
     return 128 * D * deg0 * int(round(math.log2(D))) + 192 * (D - 1)
 
 
+def level_bytes(D, deg0, lev):
+    """One level of SURVEY 8(d)'s model: 4 n input polynomials of degree d read, 4 n/2 of degree 2d written."""
+    n, d = D >> lev, deg0 << lev
+    return 64 * (n * (d + 1) + (n // 2) * (2 * d + 1))
+
+
+def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
+    """Per-launch HIP-event times of the tree kernels (event pair around every launch, on the launch
+    stream), grouped into the stages of the tree with the algorithmic bytes of the levels each stage
+    covers.  A split level is its row kernel (KMid) plus the column kernels up to the next row kernel;
+    the leaf stage takes the levels the other launches do not account for."""
+    import re
+    if sync is None:
+        import torch
+        sync = torch.cuda.synchronize
+    acc = None
+    for _ in range(reps):
+        plan.set_launch_timing(True)
+        run_once()
+        sync()
+        lt = plan.launch_times()
+        plan.set_launch_timing(False)
+        if acc is None:
+            acc = [[n, 0.0] for n, _ in lt]
+        if len(lt) != len(acc):
+            return None
+        for a, (_, ms) in zip(acc, lt):
+            a[1] += ms / reps
+    tree = [(n, ms) for n, ms in acc if not n.startswith(("KChirp", "KResample", "KExportTm"))]
+    groups = []   # [kind, [names], us, levels]
+    for n, ms in tree:
+        base = n.split("<")[0]
+        if base in ("KCoeffs", "KCoeffsProg", "KLeaf", "KLeafMulti"):
+            kind, lv = "leaf", 0
+        elif base == "KMulti":
+            kind, lv = "fused levels " + n, int(re.findall(r"\d+", n)[-1])
+        elif base in ("KPairSchool", "KPairFft"):
+            kind, lv = "single-launch levels", 1
+        elif base == "KMid":
+            kind, lv = "split levels", 1
+        elif base == "KColFwd":
+            kind, lv = "split levels", 0
+        else:   # KColBridge*, KColInv, KFinalizeScales: belong to the level that is open
+            kind, lv = (groups[-1][0] if groups else "leaf"), 0
+        if groups and groups[-1][0] == kind:
+            g = groups[-1]
+        else:
+            g = [kind, {}, 0.0, 0]
+            groups.append(g)
+        g[1][n] = g[1].get(n, 0) + 1
+        g[2] += ms * 1e3
+        g[3] += lv
+    total_levels = int(math.log2(D))
+    rest = total_levels - sum(g[3] for g in groups)
+    for g in groups:
+        if g[0] == "leaf":
+            g[3] += rest
+    out, lev = [], 0
+    for kind, names, us, lv in groups:
+        by = B * sum(level_bytes(D, deg0, l) for l in range(lev, lev + lv))
+        gbs = by / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        out.append({"stage": kind, "launches": names, "levels": [lev, lev + lv - 1], "us": round(us, 1),
+                    "algorithmic_bytes": by, "GB/s": round(gbs, 1), "frac": round(gbs / 8000.0, 4)})
+        lev += lv
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,11 +273,12 @@ def main():
             # separate passes, FETCH doubled as the microarch guide prescribes); see profiles/
             with open(tpath) as f:
                 traffic = json.load(f)["tree_hbm_bytes_per_transform"]
+        stages = launch_breakdown(plan, lambda: transform(outs[0].data_ptr()), reps, B, D, deg0)
         roof = {"bound": "hbm", "kernel": "poly_fmult2x2 tree (coefficients + all level launches of one transform)",
                 "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
-                "chirpz_epilogue_ms": round(float(chirp_ms), 4)}
+                "chirpz_epilogue_ms": round(float(chirp_ms), 4), "stages": stages}
         if not args.no_cpu_baseline:
             from oracle import load_oracle
             orc = load_oracle()

@@ -74,7 +74,8 @@ EXPORTED = [
     "fnft__nse_fscatter_numel", "fnft__nse_fscatter", "fnft_amd_device_count",
     "fnft_amd_last_error", "fnft_amd_plan_create", "fnft_amd_plan_create_sub", "fnft_amd_plan_destroy",
     "fnft_amd_plan_workspace_bytes", "fnft_amd_nsev_contspec_device", "fnft_amd_plan_finish",
-    "fnft_amd_plan_last_ms", "fnft_amd_plan_set_timing", "fnft_amd_plan_get_transfer_matrix",
+    "fnft_amd_plan_last_ms", "fnft_amd_plan_set_timing", "fnft_amd_plan_set_launch_timing",
+    "fnft_amd_plan_launch_count", "fnft_amd_plan_launch_ms", "fnft_amd_plan_get_transfer_matrix",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -155,6 +156,12 @@ def load(path=None):
     L.fnft_amd_plan_last_ms.argtypes = [vp, C.c_int]
     L.fnft_amd_plan_set_timing.restype = None
     L.fnft_amd_plan_set_timing.argtypes = [vp, C.c_int]
+    L.fnft_amd_plan_set_launch_timing.restype = None
+    L.fnft_amd_plan_set_launch_timing.argtypes = [vp, C.c_int]
+    L.fnft_amd_plan_launch_count.restype = C.c_size_t
+    L.fnft_amd_plan_launch_count.argtypes = [vp]
+    L.fnft_amd_plan_launch_ms.restype = dbl
+    L.fnft_amd_plan_launch_ms.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_size_t]
     L.fnft_amd_plan_get_transfer_matrix.restype = i32
     L.fnft_amd_plan_get_transfer_matrix.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(i32)]
     if path is None:
@@ -376,6 +383,18 @@ class KdvvPlan:
     def set_timing(self, on=True):
         self.L.fnft_amd_plan_set_timing(self.h, 1 if on else 0)
 
+    def set_launch_timing(self, on=True):
+        self.L.fnft_amd_plan_set_launch_timing(self.h, 1 if on else 0)
+
+    def launch_times(self):
+        """[(kernel name, ms)] of every launch since set_launch_timing(True); the stream must be idle."""
+        out = []
+        buf = C.create_string_buffer(128)
+        for i in range(int(self.L.fnft_amd_plan_launch_count(self.h))):
+            ms = float(self.L.fnft_amd_plan_launch_ms(self.h, i, buf, len(buf)))
+            out.append((buf.value.decode(), ms))
+        return out
+
     def last_ms(self, which=2):
         return float(self.L.fnft_amd_plan_last_ms(self.h, which))
 
@@ -424,6 +443,18 @@ class Plan:
 
     def set_timing(self, on=True):
         self.L.fnft_amd_plan_set_timing(self.h, 1 if on else 0)
+
+    def set_launch_timing(self, on=True):
+        self.L.fnft_amd_plan_set_launch_timing(self.h, 1 if on else 0)
+
+    def launch_times(self):
+        """[(kernel name, ms)] of every launch since set_launch_timing(True); the stream must be idle."""
+        out = []
+        buf = C.create_string_buffer(128)
+        for i in range(int(self.L.fnft_amd_plan_launch_count(self.h))):
+            ms = float(self.L.fnft_amd_plan_launch_ms(self.h, i, buf, len(buf)))
+            out.append((buf.value.decode(), ms))
+        return out
 
     def last_ms(self, which=2):
         return float(self.L.fnft_amd_plan_last_ms(self.h, which))

@@ -45,6 +45,11 @@ struct HipBackend {
     static constexpr int kMarks = 4;
     hipEvent_t ev[kMarks] = {nullptr, nullptr, nullptr, nullptr};
     bool timing = false;
+    // per-launch timers (bench.py's per-kernel roofline): an event pair around every launch while enabled
+    struct LaunchRec { const char *name; hipEvent_t a, b; };
+    std::vector<LaunchRec> launches;
+    size_t launches_used = 0;
+    bool launch_timing = false;
 
     void *alloc(size_t b)
     {
@@ -89,6 +94,20 @@ struct HipBackend {
     {
         for (int i = 0; i < kMarks; i++)
             if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; }
+        for (auto &r : launches) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        launches.clear();
+        launches_used = 0;
+    }
+    LaunchRec *next_launch_rec(const char *name)
+    {
+        if (launches_used == launches.size()) {
+            LaunchRec r{name, nullptr, nullptr};
+            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+            launches.push_back(r);
+        }
+        LaunchRec *r = &launches[launches_used++];
+        r->name = name;
+        return r;
     }
 
     template <class K> void run(int gx, int gy, const typename K::Params &p)
@@ -101,8 +120,11 @@ struct HipBackend {
             attr_done = true;
         }
         if (gx <= 0 || gy <= 0) return;
+        LaunchRec *rec = launch_timing ? next_launch_rec(__PRETTY_FUNCTION__) : nullptr;
+        if (rec) (void)hipEventRecord(rec->a, stream);
         hipLaunchKernelGGL(kernel_entry<K>, dim3((unsigned)gx, (unsigned)gy), dim3(K::THREADS), lds,
                            stream, p);
+        if (rec) (void)hipEventRecord(rec->b, stream);
         if (!hip_ok(hipGetLastError(), "kernel launch")) failed = true;
     }
 };
@@ -204,6 +226,37 @@ double fnft_amd_plan_last_ms(const fnft_amd_plan_t *plan, int which)
     case 2: return plan->be.elapsed_ms(0, 2);
     default: return -1.0;
     }
+}
+
+void fnft_amd_plan_set_launch_timing(fnft_amd_plan_t *plan, int enabled)
+{
+    if (!plan) return;
+    plan->be.launch_timing = enabled != 0;
+    plan->be.launches_used = 0;
+}
+
+FNFT_UINT fnft_amd_plan_launch_count(const fnft_amd_plan_t *plan)
+{
+    return plan ? plan->be.launches_used : 0;
+}
+
+double fnft_amd_plan_launch_ms(const fnft_amd_plan_t *plan, FNFT_UINT i, char *name, FNFT_UINT name_cap)
+{
+    if (!plan || i >= plan->be.launches_used) return -1.0;
+    const HipBackend::LaunchRec &r = plan->be.launches[i];
+    if (name && name_cap) {
+        // __PRETTY_FUNCTION__ of run<K>: "... [K = KMid<2>]"
+        const char *k = strstr(r.name, "K = ");
+        k = k ? k + 4 : r.name;
+        size_t n = strlen(k);
+        if (n && k[n - 1] == ']') n--;
+        if (n >= name_cap) n = name_cap - 1;
+        memcpy(name, k, n);
+        name[n] = 0;
+    }
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return -1.0;
+    return (double)ms;
 }
 
 FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, void *d_contspec,

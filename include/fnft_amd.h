@@ -255,6 +255,13 @@ FNFT_INT fnft_amd_plan_finish(fnft_amd_plan_t *plan, void *stream);
 double fnft_amd_plan_last_ms(const fnft_amd_plan_t *plan, int which);
 /* Enable/disable the per-stage event timers (they add two event records per stage). */
 void fnft_amd_plan_set_timing(fnft_amd_plan_t *plan, int enabled);
+/* Per-launch timers (measurement only; no counterpart in the reference): while enabled every kernel
+ * launch of the plan is bracketed by a HIP event pair on the launch stream.  Enabling resets the
+ * list; after the stream has been synchronised, launch i of the calls since then is read back as
+ * (kernel name, duration in ms).  launch_ms returns -1 for an index out of range. */
+void fnft_amd_plan_set_launch_timing(fnft_amd_plan_t *plan, int enabled);
+FNFT_UINT fnft_amd_plan_launch_count(const fnft_amd_plan_t *plan);
+double fnft_amd_plan_launch_ms(const fnft_amd_plan_t *plan, FNFT_UINT i, char *name, FNFT_UINT name_cap);
 
 /* Transfer matrix of the last call (device pointers into the plan's workspace, signal b):
  * coefficient arrays in the reference's result layout [r11|r12|r21|r22], each deg+1, highest

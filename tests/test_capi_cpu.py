@@ -181,3 +181,27 @@ def test_kdvv_defaults_and_validation(capi):
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization="CF4_2")[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization=99)[0] == -2
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1])[0] == capi.FNFT_EC_OTHER          # no GPU here
+
+
+def test_bench_launch_breakdown_assigns_every_level_once():
+    """bench.py's per-stage roofline: the stages of a 2^20 MODAL transform cover levels 0..19 exactly
+    once and their algorithmic bytes add up to SURVEY 8(d)'s closed form."""
+    import bench
+
+    class FakePlan:
+        seq = (["KLeafMulti<1, 3>", "KMulti<128, 3>", "KMulti<1024, 3>"]
+               + sum((["KMid<2>", "KColBridge2<%d>" % (4 << i)] for i in range(7)), [])
+               + ["KMid<2>", "KColInv<512>", "KFinalizeScales", "KChirpColFwd<512, false>", "KChirpRows",
+                  "KChirpColInv<512, false, false>"])
+
+        def set_launch_timing(self, on):
+            pass
+
+        def launch_times(self):
+            return [(n, 0.01) for n in self.seq]
+
+    D = 1 << 20
+    st = bench.launch_breakdown(FakePlan(), lambda: None, 2, 1, D, 1, sync=lambda: None)
+    assert [s["levels"] for s in st] == [[0, 5], [6, 8], [9, 11], [12, 19]]
+    assert sum(s["algorithmic_bytes"] for s in st) == bench.bytes_tree(D, 1) == 2885680960
+    assert st[-1]["launches"]["KMid<2>"] == 8 and "KChirpRows" not in st[-1]["launches"]
