@@ -126,3 +126,126 @@ def transform_xi_grid(q: Optional[np.ndarray], T, XI, M: int,
         return None
     arr = full.numpy().reshape(M, 2 * n_parts).view(np.complex128)   # [M, n_parts]
     return np.ascontiguousarray(arr.T).reshape(n_parts * M)
+
+
+# ---- one signal, sample axis cut into contiguous blocks ------------------
+# The transfer matrix of the whole signal is the ordered product of the transfer matrices of its
+# blocks (sample D-1 is the leftmost factor, fnft__akns_fscatter.c:120).  Rank g builds the sub-tree
+# of samples [g*D/G, (g+1)*D/G) -- a 2x2 polynomial matrix of degree D*deg0/G and its exponent W_g --,
+# the G matrices meet in ONE gather, and the root runs the last log2(G) levels and the evaluation on
+# the xi-grid.  Nothing here computes: the three steps are injected (`SampleAxisEngine`; the C-ABI
+# seams fnft__nse_fscatter / fnft__poly_fmult2x2 / fnft__poly_chirpz in production, stand-ins in the
+# CPU tests).  For the splitting schemes with upsampling factor 1 (the 2SPLIT* family).
+class SampleAxisEngine:
+    """subtree(q_block, eps_t) -> (tm[4, d+1], W); combine(deg, n, p[4, n*(deg+1)]) -> (tm[4, n*deg+1], W);
+    chirpz(p[N], A, V, M) -> H[M]; deg0 = polynomial degree of one sample's matrix; shifted = the
+    discretization is 2SPLIT2A or 2SPLIT2_MODAL (extra eps_t/deg0 in two of the phase factors)."""
+
+    def __init__(self, subtree, combine, chirpz, deg0: int, shifted: bool):
+        self.subtree, self.combine, self.chirpz = subtree, combine, chirpz
+        self.deg0, self.shifted = int(deg0), bool(shifted)
+
+
+def capi_sample_axis_engine(discretization: str, kappa: int, deg0: int) -> SampleAxisEngine:
+    """The production engine: the private-layer seams of the C ABI (include/fnft_amd.h), GPU only."""
+    from . import capi
+
+    def chk(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s rc=%d (%s)" % (what, rc, capi.last_error()))
+
+    def subtree(qb, eps_t):
+        rc, _, tm, W = capi.nse_fscatter(qb, eps_t, kappa, discretization)
+        chk(rc, "fnft__nse_fscatter")
+        return tm, W
+
+    def combine(deg, n, p):
+        rc, _, tm, W = capi.poly_fmult2x2(deg, n, p)
+        chk(rc, "fnft__poly_fmult2x2")
+        return tm, W
+
+    def chirpz(p, A, V, M):
+        rc, H = capi.poly_chirpz(p, A, V, M)
+        chk(rc, "fnft__poly_chirpz")
+        return H
+
+    return SampleAxisEngine(subtree, combine, chirpz, deg0, discretization in ("2SPLIT2A", "2SPLIT2_MODAL"))
+
+
+def contspec_from_transfer_matrix(tm: np.ndarray, W: int, D: int, T, XI, M: int, eng: SampleAxisEngine):
+    """Host epilogue on the root: [rho | a | b] (contspec_type BOTH) from the transfer matrix of the whole
+    signal.  Follows src/fnft_nsev.c:744-891: z-grid parameters (:822-827, lambda -> z of
+    fnft__akns_discretization.c:204-219), chirp-z on entries 11 and 21 (:829-833), phase factors of
+    fnft__nse_discretization.c:240-379 with boundary coefficient 0.5, epilogue :849-876."""
+    eps_t = (T[1] - T[0]) / (D - 1)
+    eps_xi = (XI[1] - XI[0]) / (M - 1)
+    V = np.exp(2j * eps_xi * eps_t / eng.deg0)
+    A = np.exp(-2j * XI[0] * eps_t / eng.deg0)
+    H11 = np.asarray(eng.chirpz(tm[0], A, V, M))
+    H21 = np.asarray(eng.chirpz(tm[2], A, V, M))
+    if np.any(H11 == 0):
+        raise ZeroDivisionError("a(xi) = 0 on the grid (FNFT_EC_DIV_BY_ZERO)")
+    sh = eps_t / eng.deg0 if eng.shifted else 0.0
+    tp, tm_ = T[1] + 0.5 * eps_t, T[0] - 0.5 * eps_t
+    pf_rho = -2.0 * tp + sh
+    pf_a = -eps_t * D + tp - tm_
+    pf_b = -eps_t * D - tp - tm_ + sh
+    xi = XI[0] + eps_xi * np.arange(M)
+    scale = 2.0 ** W
+    return np.concatenate([H21 * np.exp(1j * xi * pf_rho) / H11,
+                           H11 * scale * np.exp(1j * xi * pf_a),
+                           H21 * scale * np.exp(1j * xi * pf_b)])
+
+
+def combine_block_matrices(tms, Ws, eng: SampleAxisEngine):
+    """Root side of the sample-axis split: block matrices tms[g] [4, d+1] (g = position of the block in
+    the signal) with exponents Ws[g] -> (transfer matrix of the whole signal, its exponent)."""
+    G = len(tms)
+    if G == 1:
+        return np.asarray(tms[0]), int(Ws[0])
+    d = tms[0].shape[1] - 1
+    # fnft__poly_fmult2x2 input layout: entry-major, factor j of the product in block j; the last
+    # block of samples is the leftmost factor
+    p = np.stack([np.concatenate([tms[G - 1 - j][e] for j in range(G)]) for e in range(4)])
+    tm_all, Wc = eng.combine(d, G, p)
+    return np.asarray(tm_all), int(sum(Ws)) + int(Wc)
+
+
+def transform_sample_axis(q: Optional[np.ndarray], T, XI, M: int, eng: SampleAxisEngine, dst: int = 0, group=None):
+    """Root holds the signal q [D] complex128 (others pass None); D must be a multiple of the world
+    size (the root's product needs factors of equal degree).  Scatter the blocks, rank g reduces its
+    block to one matrix, one gather, the root multiplies the G matrices in the reference's order and
+    evaluates.  Returns [rho | a | b] (3*M) on the root, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    meta = [int(q.shape[0])] if rank == dst else [None]
+    dist.broadcast_object_list(meta, src=dst, group=group)
+    D = meta[0]
+    if D % world or D // world < 1:
+        raise ValueError("sample-axis sharding needs D to be a multiple of the world size")
+    Db = D // world
+    eps_t = (T[1] - T[0]) / (D - 1)          # the step of the WHOLE grid, not of the block
+    recv = torch.zeros((Db, 2), dtype=torch.float64)
+    chunks = None
+    if rank == dst:
+        v = torch.from_numpy(np.ascontiguousarray(q, dtype=np.complex128).view(np.float64).reshape(D, 2))
+        chunks = [v[r * Db:(r + 1) * Db].contiguous() for r in range(world)]
+    dist.scatter(recv, chunks, src=dst, group=group)
+    tm, W = eng.subtree(recv.numpy().reshape(2 * Db).view(np.complex128), eps_t)
+    d = Db * eng.deg0
+    tm = np.asarray(tm, np.complex128)
+    if tm.shape != (4, d + 1):
+        raise ValueError("sub-tree returned shape %r, expected (4, %d)" % (tm.shape, d + 1))
+    # one row per rank: the four coefficient arrays, then the exponent
+    row = np.concatenate([tm.reshape(-1).view(np.float64), [float(W)]])
+    full = gather_shards(torch.from_numpy(row).reshape(1, -1), world, dst=dst, group=group)
+    if full is None:
+        return None
+    rows = full.numpy()
+    Ws = [int(rows[g, -1]) for g in range(world)]
+    tms = [np.ascontiguousarray(rows[g, :-1]).view(np.complex128).reshape(4, d + 1) for g in range(world)]
+    tm_all, W_all = combine_block_matrices(tms, Ws, eng)
+    return contspec_from_transfer_matrix(np.asarray(tm_all), W_all, D, T, XI, M, eng)

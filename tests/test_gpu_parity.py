@@ -562,6 +562,31 @@ def test_xi_grid_slices_match_full_grid(capi):
             assert S.rel_err(part[j], full[j, lo:lo + M_r]) < 2 * D * M * 2.2e-16
 
 
+def test_sample_axis_blocks_match_whole_signal(capi, oracle):
+    """SURVEY 8e-ii on one GPU: the block matrices an 8-rank (4-rank) job would build, one after the
+    other through the fnft__nse_fscatter seam, multiplied on the root through fnft__poly_fmult2x2 and
+    evaluated through fnft__poly_chirpz + the host epilogue, against fnft_nsev on the whole signal and
+    against the oracle."""
+    from fnft_amd import sharding
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    for D, M, G, disc, deg0 in ((1 << 14, 999, 8, "2SPLIT2_MODAL", 1), (6000, 512, 4, "2SPLIT4B", 2)):
+        q = S.sech_focusing(D)
+        eng = sharding.capi_sample_axis_engine(disc, 1, deg0)
+        eps_t = (T[1] - T[0]) / (D - 1)
+        Db = D // G
+        blocks = [eng.subtree(q[g * Db:(g + 1) * Db], eps_t) for g in range(G)]
+        tm, W = sharding.combine_block_matrices([b[0] for b in blocks], [b[1] for b in blocks], eng)
+        assert tm.shape == (4, D * deg0 + 1)
+        cs = sharding.contspec_from_transfer_matrix(tm, W, D, T, XI, M, eng).reshape(3, M)
+        rc, full = capi.fnft_nsev(q, T, M, XI, discretization=disc, contspec_type="BOTH")
+        assert rc == 0
+        rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc=disc, cstype="BOTH")
+        assert rc2 == 0
+        for j in range(3):
+            assert S.rel_err(cs[j], full.reshape(3, M)[j]) < 2e-11
+            assert S.rel_err(cs[j], ref.reshape(3, M)[j]) < 2e-11
+
+
 def test_concurrent_host_threads(capi, oracle):
     """SURVEY 8b threading contract: the drop-in entry points may be called from several host threads
     at once (own opts per thread).  ctypes releases the GIL, so these calls really overlap; every

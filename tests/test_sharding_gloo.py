@@ -128,3 +128,59 @@ def test_xi_shard_ranges():
     assert np.allclose(pts, XI[0] + np.arange(M) * eps, atol=1e-15)
     with pytest.raises(ValueError):
         sharding.xi_shard(XI, 5, 3, 0)
+
+
+# ---- sample-axis sharding of one signal, oracle as the per-rank engine --------------
+def _oracle_sample_axis_engine(disc, deg0):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import load_oracle
+    orc = load_oracle()
+
+    def subtree(qb, eps_t):
+        rc, _, tm, W = orc.nse_fscatter(qb, eps_t, 1, disc)
+        assert rc == 0
+        return tm, W
+
+    def combine(deg, n, p):
+        _, tm, W = orc.poly_fmult2x2(deg, n, p)
+        return tm, W
+
+    return orc, sharding.SampleAxisEngine(subtree, combine, orc.poly_chirpz, deg0,
+                                          disc in ("2SPLIT2A", "2SPLIT2_MODAL"))
+
+
+def _sample_axis_worker(rank, world, port, D, M, disc, deg0, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T, XI = [-25.0, 25.0], [-1.4, 1.6]
+        t = T[0] + np.arange(D) * (T[1] - T[0]) / (D - 1)
+        sig = (3.2j / np.cosh(t) * np.exp(0.3j * t)).astype(np.complex128) if rank == 0 else None
+        orc, eng = _oracle_sample_axis_engine(disc, deg0)
+        res = sharding.transform_sample_axis(sig, T, XI, M, eng, dst=0)
+        if rank == 0:
+            rc, ref = orc.fnft_nsev(sig, T, M, XI, kappa=1, disc=disc, cstype="BOTH")
+            err = float(np.sum(np.abs(res - ref)) / np.sum(np.abs(ref)))
+            q.put(rc == 0 and err < 1e-12 and res.shape == (3 * M,))
+        else:
+            q.put(res is None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,D,disc,deg0", [(2, 256, "2SPLIT2_MODAL", 1), (2, 192, "2SPLIT4B", 2),
+                                               (4, 256, "2SPLIT4B", 2)])
+def test_sample_axis_sharding(world, D, disc, deg0):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sample_axis_worker, args=(r, world, port, D, 33, disc, deg0, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results)
