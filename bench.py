@@ -99,7 +99,7 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
     for kind, names, us, lv in groups:
         by = B * sum(level_bytes(D, deg0, l) for l in range(lev, lev + lv))
         gbs = by / (us * 1e-6) / 1e9 if us > 0 else 0.0
-        out.append({"stage": kind, "launches": names, "levels": [lev, lev + lv - 1], "us": round(us, 1),
+        out.append({"stage": kind, "launches": names, "levels": ([lev, lev + lv - 1] if lv else None), "us": round(us, 1),
                     "algorithmic_bytes": by, "GB/s": round(gbs, 1), "frac": round(gbs / 8000.0, 4)})
         lev += lv
     return out

@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    m = re.match(r"void kernel_entry<(.*) >\(", name)
+    m = re.match(r"void kernel_entry<(.*)>\(", name)
     return m.group(1).strip() if m else name
 
 
@@ -29,8 +29,9 @@ def main():
         print("|---|---|---|---|---|---|---|---|")
         for s in line["roofline"]["stages"]:
             rp = sum(avg.get(k, float("nan")) * c for k, c in s["launches"].items())
-            print("| %s | %d-%d | %s | %.1f | %.1f | %.1f | %.0f | %.3f |" % (
-                s["stage"], s["levels"][0], s["levels"][1],
+            lv = s["levels"] or ["-", "-"]
+            print("| %s | %s-%s | %s | %.1f | %.1f | %.1f | %.0f | %.3f |" % (
+                s["stage"], lv[0], lv[1],
                 ", ".join("%s x%d" % kc for kc in s["launches"].items()), s["us"], rp,
                 s["algorithmic_bytes"] / 1e6, s["GB/s"], s["frac"]))
 
