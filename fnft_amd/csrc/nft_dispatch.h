@@ -213,11 +213,14 @@ template <int N1> struct KColBridge2 {   // spectral doubling: same tiling as th
     static constexpr size_t lds_bytes() { return C::lds_bytes(); }
     static FA_DEV void body(const Params &p) { body_col_bridge2<N1, C::R, C::BC, C::DB>(p); }
 };
+#ifndef FA_MID_R
+#define FA_MID_R 8   // points per lane of the row kernel (4: 512 lanes per row, 4 waves per SIMD)
+#endif
 template <int NE> struct KMid {
     using Params = BigLevel;
-    static constexpr int R = 8;
+    static constexpr int R = FA_MID_R;
     static constexpr int THREADS = kRowTree / R;
-    static constexpr int MIN_WAVES = 2;
+    static constexpr int MIN_WAVES = (R == 4) ? 4 : 2;
     static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_mid<kRowTree, R, NE>(p); }
 };
