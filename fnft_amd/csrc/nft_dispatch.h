@@ -220,7 +220,10 @@ template <int NE> struct KMid {
     using Params = BigLevel;
     static constexpr int R = FA_MID_R;
     static constexpr int THREADS = kRowTree / R;
-    static constexpr int MIN_WAVES = (R == 4) ? 4 : 2;
+#ifndef FA_MID4_WAVES
+#define FA_MID4_WAVES 1   // general 4-entry form: 1 = 394 VGPRs, no spills (2: 186 spilled); cfg 5 split levels 6.35 -> 6.17 ms
+#endif
+    static constexpr int MIN_WAVES = (R == 4) ? 4 : (NE == 4 ? FA_MID4_WAVES : 2);
     static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_mid<kRowTree, R, NE>(p); }
 };
