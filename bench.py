@@ -279,7 +279,7 @@ def main():
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
                 "chirpz_epilogue_ms": round(float(chirp_ms), 4), "stages": stages}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU checker is timed at N = 1 only
             from oracle import load_oracle
             orc = load_oracle()
             Dc = min(D, 1 << 20)
