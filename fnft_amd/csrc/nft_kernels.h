@@ -682,8 +682,11 @@ struct TailSet {
 };
 FA_DEV cplx tail_product_general(const TailSet &t, int e)
 {
-    const int row = e >> 1, col = e & 1;
-    return cfma(t.tA[2 * row + 1], t.tB[2 + col], t.tA[2 * row] * t.tB[col]);
+    // selects, not runtime subscripts: a dynamically indexed TailSet would live in scratch memory
+    const bool row = (e >> 1) != 0, col = (e & 1) != 0;
+    const cplx a0 = row ? t.tA[2] : t.tA[0], a1 = row ? t.tA[3] : t.tA[1];
+    const cplx b0 = col ? t.tB[1] : t.tB[0], b1 = col ? t.tB[3] : t.tB[2];
+    return cfma(a1, b1, a0 * b0);
 }
 FA_DEV cplx tail_product_sym(const TailSet &t, int s, int kappa)
 {
