@@ -66,6 +66,7 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
             return None
         for a, (_, ms) in zip(acc, lt):
             a[1] += ms / reps
+    launch_breakdown.last_launches = [[n, round(ms * 1e3, 2)] for n, ms in acc]   # every launch, in order: [kernel, us]
     tree = [(n, ms) for n, ms in acc if not n.startswith(("KChirp", "KResample", "KExportTm"))]
     groups = []   # [kind, [names], us, levels]
     for n, ms in tree:
@@ -76,7 +77,7 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
             kind, lv = "fused levels " + n, int(re.findall(r"\d+", n)[-1])
         elif base in ("KPairSchool", "KPairFft"):
             kind, lv = "single-launch levels", 1
-        elif base == "KMid":
+        elif base in ("KMid", "KMidSym"):
             kind, lv = "split levels", 1
         elif base == "KColFwd":
             kind, lv = "split levels", 0
@@ -278,7 +279,8 @@ def main():
                 "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
-                "chirpz_epilogue_ms": round(float(chirp_ms), 4), "stages": stages}
+                "chirpz_epilogue_ms": round(float(chirp_ms), 4), "stages": stages,
+                "launches_us": getattr(launch_breakdown, "last_launches", None)}
         if not args.no_cpu_baseline and world == 1:   # the CPU checker is timed at N = 1 only
             from oracle import load_oracle
             orc = load_oracle()

@@ -29,30 +29,36 @@ def needs_build():
     return _newest(deps) > os.path.getmtime(LIB)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, defs=None, out=None):
+    """defs / out: diagnostic variants (tests/gpu_debug/build_variant.py) -- extra -D flags and another
+    output path; the product library is always build() with neither."""
+    if out is None and not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+    lib = out or LIB
+    libdir = os.path.dirname(lib) if out else LIBDIR
+    os.makedirs(libdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
     objs = []
+    extra = list(defs) if defs else os.environ.get("FNFT_AMD_DEFS", "").split()
+    tag = os.path.splitext(os.path.basename(lib))[0]
     cmds = [
-        [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FNFT_AMD_DEFS", "").split() + ["-c",
-         os.path.join(CSRC, "hip_backend.hip"), "-o", os.path.join(LIBDIR, "hip_backend.o")],
+        [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + extra + ["-c",
+         os.path.join(CSRC, "hip_backend.hip"), "-o", os.path.join(libdir, tag + "_hip_backend.o" if out else "hip_backend.o")],
         [hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c",
-         os.path.join(CSRC, "fnft_nsev_host.c"), "-o", os.path.join(LIBDIR, "fnft_nsev_host.o")],
+         os.path.join(CSRC, "fnft_nsev_host.c"), "-o", os.path.join(libdir, tag + "_nsev_host.o" if out else "fnft_nsev_host.o")],
         [hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c",
-         os.path.join(CSRC, "fnft_kdvv_host.c"), "-o", os.path.join(LIBDIR, "fnft_kdvv_host.o")],
+         os.path.join(CSRC, "fnft_kdvv_host.c"), "-o", os.path.join(libdir, tag + "_kdvv_host.o" if out else "fnft_kdvv_host.o")],
     ]
     for c in cmds:
         if verbose:
             print(" ".join(c), flush=True)
         subprocess.check_call(c)
         objs.append(c[-1])
-    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -14,6 +14,10 @@
 #define FA_DEV __device__ __forceinline__
 #define FA_KERNEL __global__
 #define FA_SYNC() __syncthreads()
+// Barrier for data exchanged through LDS only: waits for this wave's LDS operations and joins the
+// workgroup barrier, but -- unlike __syncthreads(), whose release fence drains vmcnt when global
+// stores are outstanding -- lets global loads and stores in flight stay in flight across it.
+#define FA_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define FA_TID ((int)threadIdx.x)
 #define FA_BID ((int)blockIdx.x)
 #define FA_BID_Y ((int)blockIdx.y)
@@ -38,6 +42,12 @@ FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+// start delay of part of a grid: n sleep periods of ~1024 clocks for the waves that are `late`
+FA_DEV void fa_stagger(int n, bool late)
+{
+    if (late)
+        for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(16);
+}
 // value known to be the same in every lane of the wave: move it to scalar registers
 FA_DEV double fa_uniform(double x)
 {
@@ -59,6 +69,7 @@ struct fa_emu_ctx {
 };
 extern thread_local fa_emu_ctx *fa_emu;
 #define FA_SYNC() fa_emu->bar->arrive_and_wait()
+#define FA_SYNC_LDS() fa_emu->bar->arrive_and_wait()
 #define FA_TID (fa_emu->tid)
 #define FA_BID (fa_emu->bid)
 #define FA_BID_Y (fa_emu->bid_y)
@@ -82,6 +93,7 @@ FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
 FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
 FA_DEV double fa_uniform(double x) { return x; }
+FA_DEV void fa_stagger(int, bool) {}
 using std::exp;
 using std::floor;
 using std::fma;

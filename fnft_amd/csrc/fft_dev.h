@@ -186,7 +186,7 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S, bool TWC = fa
                            int &parity)
     {
         cplx *buf = DB ? lds + (size_t)parity * (size_t)(N * B) : lds;
-        if constexpr (!last && !DB) FA_SYNC();  // single buffer: previous readers must be done
+        if constexpr (!last && !DB) FA_SYNC_LDS();  // single buffer: previous readers must be done
 #pragma unroll
         for (int j = 0; j < J; j++) {
             const int u = v + (N / R) * j;
@@ -232,7 +232,7 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S, bool TWC = fa
             }
         }
         if constexpr (!last) {
-            FA_SYNC();
+            FA_SYNC_LDS();
 #pragma unroll
             for (int i = 0; i < R; i++) x[i] = buf[(size_t)lds_swz<N>(v + (N / R) * i) * B + c];
             parity ^= 1;
@@ -250,6 +250,118 @@ FA_DEV void fft_wg(cplx (&x)[R], cplx *lds, int v, int c, const cplx *__restrict
 {
     static_assert(N >= R, "fft_wg: N must be at least R");
     FftPass<N, R, B, SIGN, DB, N, 1, TWC>::run(x, lds, v, c, tw, parity);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two transforms at once, software-pipelined half a pass apart ("pair-interleaved").
+//
+// The butterflies of one sequence are independent of the LDS round trip of the other, so each
+// barrier interval holds  [LDS reads of Y issued] [butterflies of X] [LDS writes of X]  (and the
+// mirror image in the next interval): the read latency and the barrier wait of one sequence hide
+// behind the register work of the other.  With 1-2 waves per SIMD -- all the row kernels can hold
+// -- that is the latency hiding the hardware scheduler cannot provide.
+//
+// lds: two single buffers of N*B elements, bufX = lds, bufY = lds + N*B (the footprint of the
+// double-buffered single transform).  Hand-over rule: on entry nobody is still reading either
+// buffer from an earlier call's exchange EXCEPT reads that were issued before that call's last
+// barrier -- which is exactly what this function leaves behind, so consecutive calls chain without
+// extra barriers.  Intervals (p = exchange pass):
+//     [B_X(p) W_X(p)] | [R_X(p) B_Y(p) W_Y(p)] | [R_Y(p) B_X(p+1) W_X(p+1)] | ...
+// W_X(p+1) follows the barrier that follows R_X(p) of every lane; W_Y(p) follows the barrier that
+// follows R_Y(p-1) of every lane.
+// ---------------------------------------------------------------------------------------------
+template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2Pass {
+    static constexpr int r = (NCUR < R) ? NCUR : R;
+    static constexpr int J = R / r;
+    static constexpr bool last = (NCUR == r);
+
+    // radix-r butterflies (and twiddles, unless this is the last pass) of one sequence, in place:
+    // butterfly j's output k is left in x[j + J*k]
+    static FA_DEV void bfly(cplx (&x)[R], int v, const cplx *__restrict__ tw)
+    {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int u = v + (N / R) * j;
+            const int p = u / S;
+            cplx t[r];
+#pragma unroll
+            for (int k = 0; k < r; k++) t[k] = x[j + J * k];
+            RegDft<r, SIGN>::run(t);
+            if constexpr (!last) {
+                if constexpr (TWC && r == 8) {
+                    const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
+                    const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
+                    const cplx w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+                    t[4] = t[4] * w4; t[5] = t[5] * w4; t[6] = t[6] * w4; t[7] = t[7] * w4;
+                    t[1] = t[1] * w1; t[5] = t[5] * w1;
+                    t[2] = t[2] * w2; t[6] = t[6] * w2;
+                    const cplx w3 = w1 * w2;
+                    t[3] = t[3] * w3; t[7] = t[7] * w3;
+                } else if constexpr (TWC && r == 16) {
+                    const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
+                    const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
+                    const cplx w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+                    const cplx w8 = tw_dir<SIGN>(tw[(size_t)(8 * p) * S]);
+                    const cplx w3 = w1 * w2, w5 = w1 * w4, w6 = w2 * w4, w7 = w3 * w4;
+                    t[1] = t[1] * w1;  t[2] = t[2] * w2;  t[3] = t[3] * w3;  t[4] = t[4] * w4;
+                    t[5] = t[5] * w5;  t[6] = t[6] * w6;  t[7] = t[7] * w7;  t[8] = t[8] * w8;
+                    t[9] = t[9] * (w1 * w8);   t[10] = t[10] * (w2 * w8);  t[11] = t[11] * (w3 * w8);
+                    t[12] = t[12] * (w4 * w8); t[13] = t[13] * (w5 * w8);  t[14] = t[14] * (w6 * w8);
+                    t[15] = t[15] * (w7 * w8);
+                } else {
+#pragma unroll
+                    for (int k = 1; k < r; k++) t[k] = t[k] * tw_dir<SIGN>(tw[(size_t)(p * k) * S]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < r; k++) x[j + J * k] = t[k];
+        }
+    }
+    static FA_DEV void write(const cplx (&x)[R], cplx *buf, int v, int c)
+    {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int u = v + (N / R) * j;
+            const int q = u % S, p = u / S;
+#pragma unroll
+            for (int k = 0; k < r; k++) buf[(size_t)lds_swz<N>(q + S * (r * p + k)) * B + c] = x[j + J * k];
+        }
+    }
+    static FA_DEV void read(cplx (&x)[R], const cplx *buf, int v, int c)
+    {
+#pragma unroll
+        for (int i = 0; i < R; i++) x[i] = buf[(size_t)lds_swz<N>(v + (N / R) * i) * B + c];
+    }
+
+    // entered with X's pass-p inputs in registers and Y's pass-p inputs READ ISSUED (or, for the
+    // first pass, in registers)
+    static FA_DEV void run(cplx (&x)[R], cplx (&y)[R], cplx *bufX, cplx *bufY, int v, int c,
+                           const cplx *__restrict__ tw)
+    {
+        bfly(x, v, tw);
+        if constexpr (last) {
+            bfly(y, v, tw);
+        } else {
+            write(x, bufX, v, c);
+            FA_SYNC_LDS();
+            read(x, bufX, v, c);
+            bfly(y, v, tw);
+            write(y, bufY, v, c);
+            FA_SYNC_LDS();
+            read(y, bufY, v, c);
+            Fft2Pass<N, R, B, SIGN, NCUR / r, S * r, TWC>::run(x, y, bufX, bufY, v, c, tw);
+        }
+    }
+};
+template <int N, int R, int B, int SIGN, int S, bool TWC> struct Fft2Pass<N, R, B, SIGN, 1, S, TWC> {
+    static FA_DEV void run(cplx (&)[R], cplx (&)[R], cplx *, cplx *, int, int, const cplx *__restrict__) {}
+};
+
+template <int N, int R, int B, int SIGN, bool TWC = false>
+FA_DEV void fft_wg2(cplx (&x)[R], cplx (&y)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw)
+{
+    static_assert(N >= R, "fft_wg2: N must be at least R");
+    Fft2Pass<N, R, B, SIGN, N, 1, TWC>::run(x, y, lds, lds + (size_t)N * B, v, c, tw);
 }
 
 // ---------------------------------------------------------------------------------------------

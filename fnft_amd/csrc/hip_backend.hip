@@ -140,7 +140,11 @@ struct fnft_amd_plan {
     std::mutex mtx;
 };
 
-static bool ensure_device(int device)
+// Device rule of the library (documented in include/fnft_amd.h): the host-pointer entry points
+// compute on the calling thread's CURRENT HIP device (hipGetDevice; what torch.cuda.set_device or
+// hipSetDevice selected) and never change it; device-resident plans live on the device given to
+// fnft_amd_plan_create, and every plan call restores the caller's current device before returning.
+static bool device_valid(int device)
 {
     int n = 0;
     if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
@@ -148,8 +152,37 @@ static bool ensure_device(int device)
         return false;
     }
     if (device < 0 || device >= n) { g_last_error = "device index out of range"; return false; }
-    return hip_ok(hipSetDevice(device), "hipSetDevice");
+    return true;
 }
+// the calling thread's current device, or -1 (no usable device)
+static int current_device()
+{
+    int n = 0, dev = 0;
+    if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
+        if (g_last_error.empty()) g_last_error = "no HIP device";
+        return -1;
+    }
+    if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return -1;
+    return dev;
+}
+// selects `device` for the scope and puts the caller's device back afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device)
+    {
+        if (!device_valid(device)) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == device) || hip_ok(hipSetDevice(device), "hipSetDevice");
+    }
+    ~DeviceGuard()
+    {
+        if (ok && prev >= 0) {
+            int now = -1;
+            if (hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+        }
+    }
+};
 
 extern "C" {
 
@@ -177,7 +210,8 @@ FNFT_INT fnft_amd_plan_create_sub(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT
     const int ups = nft_nse_upsampling((int)discretization);
     if (ups == 1 && nskip != 1) return FNFT_EC_NOT_YET_IMPLEMENTED;
     if (ups == 2 && D <= 2) return FNFT_EC_INVALID_ARGUMENT;   // fnft__misc.c:331-332
-    if (!ensure_device(device)) return FNFT_EC_OTHER;
+    DeviceGuard dg(device);
+    if (!dg.ok) return FNFT_EC_OTHER;
     fnft_amd_plan *P = new (std::nothrow) fnft_amd_plan();
     if (!P) return FNFT_EC_NOMEM;
     P->device = device;
@@ -186,7 +220,9 @@ FNFT_INT fnft_amd_plan_create_sub(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT
     P->pl = new (std::nothrow) Plan(P->be, Dtree, M, batch, akns, nft_akns_degree(akns));
     if (!P->pl) { delete P; return FNFT_EC_NOMEM; }
     P->pl->set_front((size_t)D, (size_t)nskip, ups);
+#ifdef FNFT_AMD_ABLATION   // diagnostic builds only; the product library reads no environment variable
     if (const char *dbg = getenv("FNFT_AMD_DBG")) P->pl->dbg_flags = atoi(dbg);
+#endif
     const int rc = P->pl->init();
     if (rc != NFT_SUCCESS || P->be.failed) {
         P->pl->destroy();
@@ -202,7 +238,7 @@ FNFT_INT fnft_amd_plan_create_sub(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT
 void fnft_amd_plan_destroy(fnft_amd_plan_t *plan)
 {
     if (!plan) return;
-    (void)hipSetDevice(plan->device);
+    DeviceGuard dg(plan->device);
     (void)hipDeviceSynchronize();
     plan->pl->destroy();
     plan->be.destroy_events();
@@ -211,6 +247,42 @@ void fnft_amd_plan_destroy(fnft_amd_plan_t *plan)
 }
 
 FNFT_UINT fnft_amd_plan_workspace_bytes(const fnft_amd_plan_t *plan) { return plan ? plan->pl->bytes : 0; }
+
+int fnft_amd_plan_device(const fnft_amd_plan_t *plan) { return plan ? plan->device : -1; }
+
+#ifdef FNFT_AMD_TUNING
+// diagnostic builds only: tuning parameters of a plan (which: 0 = row-kernel stagger)
+extern "C" int fnft_amd_debug_tune(fnft_amd_plan_t *plan, int which, int value)
+{
+    if (!plan) return -1;
+    if (which == 0) plan->pl->tune_stagger = value;
+    return 0;
+}
+#endif
+
+#ifdef FNFT_AMD_STAMPS
+// diagnostic builds only: stamp the row kernel of split level `level` (16 u64 per wave, 4096 waves max);
+// read back after the stream has been synchronised
+extern "C" int fnft_amd_debug_stamps(fnft_amd_plan_t *plan, int level, unsigned long long *host, size_t n)
+{
+    if (!plan) return -1;
+    DeviceGuard dg(plan->device);
+    Plan &pl = *plan->pl;
+    if (!pl.dbg_stamps) {
+        pl.dbg_stamps = (unsigned long long *)plan->be.alloc((size_t)4096 * 16 * 8);
+        if (!pl.dbg_stamps) return -1;
+        (void)hipMemset(pl.dbg_stamps, 0, (size_t)4096 * 16 * 8);
+    }
+    pl.stamp_level = level;
+    if (host && n) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(host, pl.dbg_stamps, n * 8, hipMemcpyDeviceToHost);
+    }
+    return 0;
+}
+#endif
+
+int fnft_amd_current_device(void) { return current_device(); }
 
 void fnft_amd_plan_set_timing(fnft_amd_plan_t *plan, int enabled)
 {
@@ -270,7 +342,8 @@ FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, v
     const int cst = (int)contspec_type;
     if (cst < 0 || cst > 2) return FNFT_EC_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(plan->mtx);
-    if (!hip_ok(hipSetDevice(plan->device), "hipSetDevice")) return FNFT_EC_OTHER;
+    DeviceGuard dg(plan->device);
+    if (!dg.ok) return FNFT_EC_OTHER;
     Plan &pl = *plan->pl;
     plan->be.stream = (hipStream_t)stream;
     plan->be.failed = false;
@@ -301,7 +374,8 @@ FNFT_INT fnft_amd_kdvv_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UIN
     if (kd < 0) return FNFT_EC_INVALID_ARGUMENT;
     if (kd > (int)fnft_kdv_discretization_2SPLIT8B) return FNFT_EC_NOT_YET_IMPLEMENTED;
     const int akns = kd + 1;   // same scheme names, fnft__kdv_discretization.c:86-150
-    if (!ensure_device(device)) return FNFT_EC_OTHER;
+    DeviceGuard dg(device);
+    if (!dg.ok) return FNFT_EC_OTHER;
     fnft_amd_plan *P = new (std::nothrow) fnft_amd_plan();
     if (!P) return FNFT_EC_NOMEM;
     P->device = device;
@@ -328,7 +402,8 @@ FNFT_INT fnft_amd_kdvv_contspec_device(fnft_amd_plan_t *plan, const void *d_u, v
     if (!plan || plan->kdv_disc < 0 || !d_u || !d_contspec || !T || !(T[0] < T[1]) || !XI || !(XI[0] < XI[1]))
         return FNFT_EC_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(plan->mtx);
-    if (!hip_ok(hipSetDevice(plan->device), "hipSetDevice")) return FNFT_EC_OTHER;
+    DeviceGuard dg(plan->device);
+    if (!dg.ok) return FNFT_EC_OTHER;
     Plan &pl = *plan->pl;
     plan->be.stream = (hipStream_t)stream;
     plan->be.failed = false;
@@ -348,7 +423,7 @@ FNFT_INT fnft_amd_plan_finish(fnft_amd_plan_t *plan, void *stream)
 {
     if (!plan) return FNFT_EC_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(plan->mtx);
-    (void)hipSetDevice(plan->device);
+    DeviceGuard dg(plan->device);
     plan->be.stream = (hipStream_t)stream;
     return plan->pl->read_status();
 }
@@ -359,7 +434,7 @@ FNFT_INT fnft_amd_plan_get_transfer_matrix(fnft_amd_plan_t *plan, FNFT_UINT b,
     if (!plan || !result_host || !plan->pl->tree_valid || b >= plan->pl->batch)
         return FNFT_EC_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(plan->mtx);
-    (void)hipSetDevice(plan->device);
+    DeviceGuard dg(plan->device);
     Plan &pl = *plan->pl;
     pl.export_tm();
     const size_t per = 4 * (pl.res_deg + 1);
@@ -382,7 +457,8 @@ FNFT_UINT fnft__poly_fmult2x2_numel(const FNFT_UINT deg, const FNFT_UINT n)
 FNFT_INT fnft__poly_fmult2x2(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *const p,
                              FNFT_COMPLEX *const result, FNFT_INT *const W_ptr)
 {
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
     return api_poly_fmult2x2(be, d, n, p, result, W_ptr);
 }
@@ -391,7 +467,8 @@ FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, 
                               const double *W, const FNFT_UINT M, FNFT_COMPLEX *const result)
 {
     if (!p || M == 0 || !result || !A || !W) return FNFT_EC_INVALID_ARGUMENT;
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
     return Plan::chirpz_host(be, deg, p, {A[0], A[1]}, {W[0], W[1]}, M, result);
 }
@@ -417,7 +494,8 @@ FNFT_INT fnft__akns_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q,
     // argument checks in the reference's order, src/private/fnft__akns_fscatter.c:80-97
     if (D == 0 || !q || !r || !(eps_t > 0.0) || !result || !deg_ptr) return FNFT_EC_INVALID_ARGUMENT;
     if (nft_akns_degree((int)discretization) == 0) return FNFT_EC_INVALID_ARGUMENT;
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
     return api_akns_fscatter(be, D, q, r, eps_t, 1, result, deg_ptr, W_ptr, (int)discretization);
 }
@@ -438,7 +516,8 @@ FNFT_INT fnft__nse_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q, cons
         return FNFT_EC_INVALID_ARGUMENT;
     const int a = nft_nse_to_akns((int)discretization);
     if (a < 0) return FNFT_EC_INVALID_ARGUMENT;
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
     return api_akns_fscatter(be, D, q, nullptr, eps_t, kappa, result, deg_ptr, W_ptr, a);
 }
@@ -458,7 +537,8 @@ FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, cons
     if (D == 0 || !u || !(eps_t > 0.0) || !result || !deg_ptr) return FNFT_EC_INVALID_ARGUMENT;
     const int kd = (int)discretization;
     if (kd < 0 || kd > (int)fnft_kdv_discretization_2SPLIT8B) return FNFT_EC_INVALID_ARGUMENT;
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     std::vector<std::complex<double>> r(D, std::complex<double>(-1.0, 0.0));
     HipBackend be;
     return api_akns_fscatter(be, D, (const std::complex<double> *)u, r.data(), eps_t, 1,
@@ -471,19 +551,20 @@ FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const 
 {
     std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
     static std::mutex cache_mtx;
-    static std::map<std::tuple<size_t, size_t, int>, fnft_amd_plan *> cache;
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    static std::map<std::tuple<int, size_t, size_t, int>, fnft_amd_plan *> cache;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     fnft_amd_plan *P = nullptr;
     {
         std::lock_guard<std::mutex> lk(cache_mtx);
-        auto key = std::make_tuple((size_t)D, (size_t)M, discretization);
+        auto key = std::make_tuple(dev, (size_t)D, (size_t)M, discretization);
         auto it = cache.find(key);
         if (it == cache.end()) {
             if (cache.size() >= 4) {
                 for (auto &kv : cache) fnft_amd_plan_destroy(kv.second);
                 cache.clear();
             }
-            const FNFT_INT rc = fnft_amd_kdvv_plan_create(&P, D, M, 1, (fnft_kdv_discretization_t)discretization, 0);
+            const FNFT_INT rc = fnft_amd_kdvv_plan_create(&P, D, M, 1, (fnft_kdv_discretization_t)discretization, dev);
             if (rc != FNFT_SUCCESS) return rc;
             cache[key] = P;
         } else {
@@ -516,7 +597,8 @@ FNFT_INT fnft_amd__nsev_discspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                                       FNFT_COMPLEX *normconsts_or_residues, int *warn)
 {
     std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
     NftDiscSpec<HipBackend> ds(be);
     NftDsOpts o;
@@ -542,12 +624,13 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
 {
     std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
     static std::mutex cache_mtx;
-    static std::map<std::tuple<size_t, size_t, int, size_t>, fnft_amd_plan *> cache;
-    if (!ensure_device(0)) return FNFT_EC_OTHER;
+    static std::map<std::tuple<int, size_t, size_t, int, size_t>, fnft_amd_plan *> cache;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
     fnft_amd_plan *P = nullptr;
     {
         std::lock_guard<std::mutex> lk(cache_mtx);
-        auto key = std::make_tuple((size_t)D, (size_t)M, discretization, (size_t)nskip);
+        auto key = std::make_tuple(dev, (size_t)D, (size_t)M, discretization, (size_t)nskip);
         auto it = cache.find(key);
         if (it == cache.end()) {
             if (cache.size() >= 4) {  // keep the workspace footprint bounded
@@ -555,7 +638,7 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                 cache.clear();
             }
             const FNFT_INT rc = fnft_amd_plan_create_sub(&P, D, M, 1,
-                                                         (fnft_nse_discretization_t)discretization, 0, nskip);
+                                                         (fnft_nse_discretization_t)discretization, dev, nskip);
             if (rc != FNFT_SUCCESS) return rc;
             cache[key] = P;
         } else {

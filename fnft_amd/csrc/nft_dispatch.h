@@ -335,7 +335,7 @@ template <int N0, int STAGES> struct KMulti {
     static constexpr size_t lds_bytes()
     {
         constexpr size_t tw = (N0 * ((1 << STAGES) - 1) <= 1024) ? (size_t)N0 * ((1 << STAGES) - 1) : 0;
-        return ((size_t)(C::DB ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw) * sizeof(cplx)
+        return ((size_t)((C::DB || FA_MULTI_PAIR2) ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw) * sizeof(cplx)
                + (size_t)((C::BF + 1) & ~1) * sizeof(unsigned long long);
     }
     static FA_DEV void body(const Params &p) { body_multi_fft<N0, STAGES, C::R, C::BF, C::DB>(p); }
@@ -350,7 +350,7 @@ template <int DEG, int STAGES> struct KLeafMulti {
     static constexpr size_t lds_bytes()
     {
         constexpr size_t tw = (size_t)(2 * DEG * SPT) * ((1 << STAGES) - 1);
-        return ((size_t)(C::DB ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw + (size_t)2 * C::THREADS) * sizeof(cplx)
+        return ((size_t)((C::DB || FA_MULTI_PAIR2) ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw + (size_t)2 * C::THREADS) * sizeof(cplx)
                + (size_t)((C::BF + 1) & ~1) * sizeof(unsigned long long) + (size_t)C::THREADS * sizeof(int);
     }
     static FA_DEV void body(const Params &p) { body_leaf_multi<DEG, SPT, STAGES, C::R, C::BF, C::DB>(p); }
@@ -372,11 +372,25 @@ template <class BE> bool dispatch_multi(BE &be, const TreeLevel &L, int N, int s
 #undef X
     return false;
 }
+// symmetric row kernel with back-to-back loads and pair-interleaved transforms (body_mid_sym)
+template <bool DIRECT> struct KMidSym {
+    using Params = BigLevel;
+    static constexpr int R = FA_MID_R;
+    static constexpr int THREADS = kRowTree / R;
+    static constexpr int MIN_WAVES = (R == 4) ? 4 : (R == 16 ? 1 : 2);
+    static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_mid_sym<kRowTree, R, DIRECT>(p); }
+};
+#ifndef FA_MID_SYM
+#define FA_MID_SYM 1   // 0: the generic-IO row kernel (KMid<2>) for the symmetric form as well
+#endif
 template <class BE> void run_mid(BE &be, const BigLevel &G)
 {
     const int g = (G.L.n_in / 2) * G.N1;
     if (G.L.ne == 4) be.template run<KMid<4>>(g, 1, G);
-    else be.template run<KMid<2>>(g, 1, G);
+    else if (!FA_MID_SYM) be.template run<KMid<2>>(g, 1, G);
+    else if (G.y_direct) be.template run<KMidSym<true>>(g, 1, G);
+    else be.template run<KMidSym<false>>(g, 1, G);
 }
 template <class BE> bool dispatch_pair_fft(BE &be, const TreeLevel &L, int N)
 {

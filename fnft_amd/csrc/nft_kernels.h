@@ -23,6 +23,14 @@
 #pragma once
 #include "fft_dev.h"
 
+// Timing-ablation hooks (skip loads / transforms / stores of the pair kernels) exist only in
+// diagnostic builds made with -DFNFT_AMD_ABLATION; the product build compiles them out.
+#ifdef FNFT_AMD_ABLATION
+#define FA_DBG(x) (x)
+#else
+#define FA_DBG(x) 0
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // parameter blocks
 // ---------------------------------------------------------------------------------------------
@@ -46,7 +54,7 @@ struct TreeLevel {
     const cplx *tw;                // exp(-2 pi i j/N) table of the transform length used
     int ne;                        // stored entries per matrix: 4 general, 2 symmetric (11, 21)
     int kappa;                     // +1 focusing / -1 defocusing (symmetric form only)
-    int dbg;                       // timing ablation (tests/gpu_debug only): 1 skip transforms, 2 skip loads, 4 skip stores
+    int dbg;                       // diagnostic builds (-DFNFT_AMD_ABLATION) only: 1 skip transforms, 2 skip loads, 4 skip stores
     const cplx *twm[3];            // multi-level kernel (body_multi_fft): tables for N0, 2*N0, 4*N0
 };
 
@@ -597,7 +605,7 @@ template <int DEG> FA_DEV void body_pair_school(const TreeLevel &L)
 template <int N, int T> FA_DEV cplx *stage_twiddles(cplx *dst, const cplx *__restrict__ src)
 {
     for (int j = FA_TID; j < N; j += T) dst[j] = src[j];
-    FA_SYNC();
+    FA_SYNC_LDS();
     return dst;
 }
 
@@ -730,7 +738,7 @@ template <int N, int R, int B, int NE> struct TreeIO {
             x[i] = val;
         }
     }
-    FA_DEV int dbg() const { return L.dbg; }
+    FA_DEV int dbg() const { return FA_DBG(L.dbg); }
     FA_DEV void sink(cplx (&x)[R], cplx (&y)[R])
     {   // keeps ablated work alive: one lane may store
         double s = 0.0;
@@ -773,7 +781,7 @@ template <int N, int R, int B, int NE> struct TreeIO {
         const double inv = 1.0 / (double)N;
         cplx *stage = lds + ((N > R) ? (size_t)parity * (size_t)(N * B) : 0);
         cplx *dst = L.body_out + (size_t)e * L.plane + (size_t)P * d2;
-        if (B > 1 && N == R) FA_SYNC();  // no transform barrier separates consecutive stores
+        if (B > 1 && N == R) FA_SYNC_LDS();  // no transform barrier separates consecutive stores
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const int idx = v + (N / R) * i;
@@ -796,7 +804,7 @@ template <int N, int R, int B, int NE> struct TreeIO {
             }
         }
         if (B > 1) {
-            FA_SYNC();
+            FA_SYNC_LDS();
             const long long P0 = (long long)FA_BID * B;
             const long long nvalid = (n_out - P0 < B) ? n_out - P0 : B;
             const int total = (int)nvalid * d2;
@@ -836,7 +844,7 @@ template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const 
     // for N == R (single pass, no barrier) the group is one lane, so order is trivial.
     if (N > R) {
         if (io.active) fa_atomic_max_u64(&mx[c], dbits(io.m2));
-        FA_SYNC();
+        FA_SYNC_LDS();
     } else {
         mx[c] = dbits(io.m2);
     }
@@ -859,16 +867,28 @@ template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const 
 // NF = N0 * 2^(STAGES-1).
 // LDS: T*R transform/staging elements, then per stage the tails (2 per product), then BF maxima.
 // ---------------------------------------------------------------------------------------------
+// FA_MULTI_PAIR2: the transforms of a stage run in pairs (fft_wg2: two single LDS buffers bufX = lds,
+// bufY = lds + T*R).  The products then cross to the next stage through bufX (entry 11) and bufY
+// (entry 21): bufX is free once fft_wg2 returns (its last reads precede the final barrier), bufY after
+// the barrier that follows the entry-11 hand-over.
+#ifndef FA_MULTI_PAIR2
+#define FA_MULTI_PAIR2 1
+#endif
 template <int N, int R, int PAIRS, bool DB, bool TWC> struct MultiStage {
     // symmetric pair product of the `PAIRS` pairs held by the workgroup; on entry a11.. hold the
     // factors (natural order, zero padded), on exit c11 / c21 the cyclic products times N
     static FA_DEV void product(cplx (&a11)[R], cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], cplx *lds, int v,
                                int c, const cplx *tw, int kappa, int &parity)
     {
-        fft_wg<N, R, PAIRS, -1, DB, TWC>(a11, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, -1, DB, TWC>(a21, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, -1, DB, TWC>(b11, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, -1, DB, TWC>(b21, lds, v, c, tw, parity);
+        if constexpr (FA_MULTI_PAIR2) {
+            fft_wg2<N, R, PAIRS, -1, TWC>(a11, a21, lds, v, c, tw);
+            fft_wg2<N, R, PAIRS, -1, TWC>(b11, b21, lds, v, c, tw);
+        } else {
+            fft_wg<N, R, PAIRS, -1, DB, TWC>(a11, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, -1, DB, TWC>(a21, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, -1, DB, TWC>(b11, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, -1, DB, TWC>(b21, lds, v, c, tw, parity);
+        }
         // g[m] = exp(-2 pi i d m/N) = (-1)^m for N = 2d; m = v + (N/R) i has the parity of v (N/R even)
         const double g = ((N / R) % 2 == 0) ? ((v & 1) ? -1.0 : 1.0) : 0.0;
         const double mk = (double)(-kappa);
@@ -881,8 +901,12 @@ template <int N, int R, int PAIRS, bool DB, bool TWC> struct MultiStage {
             b11[i] = c11;
             b21[i] = c21;
         }
-        fft_wg<N, R, PAIRS, +1, DB, TWC>(b11, lds, v, c, tw, parity);
-        fft_wg<N, R, PAIRS, +1, DB, TWC>(b21, lds, v, c, tw, parity);
+        if constexpr (FA_MULTI_PAIR2) {
+            fft_wg2<N, R, PAIRS, +1, TWC>(b11, b21, lds, v, c, tw);
+        } else {
+            fft_wg<N, R, PAIRS, +1, DB, TWC>(b11, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, +1, DB, TWC>(b21, lds, v, c, tw, parity);
+        }
     }
 };
 
@@ -921,12 +945,9 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
             tA0 = ltail[(size_t)(2 * c) * 2]; tA1 = ltail[(size_t)(2 * c) * 2 + 1];
             tB0 = ltail[(size_t)(2 * c + 1) * 2]; tB1 = ltail[(size_t)(2 * c + 1) * 2 + 1];
         } else if (S == 0) {
-            const long long mA = mat0 + 2 * c;
-            const double sA = act ? L.scale_in[mA] : 0.0, sB = act ? L.scale_in[mA + 1] : 0.0;
-            tA0 = act ? L.tail_in[mA] * sA : cmake(0.0, 0.0);
-            tA1 = act ? L.tail_in[(size_t)L.n_in + mA] * sA : cmake(0.0, 0.0);
-            tB0 = act ? L.tail_in[mA + 1] * sB : cmake(0.0, 0.0);
-            tB1 = act ? L.tail_in[(size_t)L.n_in + mA + 1] * sB : cmake(0.0, 0.0);
+            // N0 = 2d: the constant terms are element d = (N0/R)*(R/2) of the zero-padded factors, i.e.
+            // register R/2 of the lanes with v == 0 -- the only lanes that use them
+            tA0 = a11[R / 2]; tA1 = a21[R / 2]; tB0 = b11[R / 2]; tB1 = b21[R / 2];
         } else {
             const cplx *tp = tails + (size_t)(S - 1) * 2 * (2 * (BF << (STAGES - 1)) / 2);
             tA0 = tp[(size_t)(2 * c) * 2]; tA1 = tp[(size_t)(2 * c) * 2 + 1];
@@ -951,8 +972,8 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
             for (int e = 0; e < 2; e++) {
                 // single buffer: wait until the last exchange has been read; double buffer: the idle
                 // one is free by the hand-over rule of fft_wg
-                cplx *stg = DB ? lds + (size_t)parity * kBufElems : lds;
-                if (!DB) FA_SYNC();
+                cplx *stg = FA_MULTI_PAIR2 ? lds + (size_t)e * kBufElems : (DB ? lds + (size_t)parity * kBufElems : lds);
+                if (!DB && !FA_MULTI_PAIR2) FA_SYNC_LDS();
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int idx = v + (N / R) * i;
@@ -962,7 +983,7 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
                     stg[(size_t)c * N + rot] = val;
                 }
                 if (v == 0) tnext[(size_t)c * 2 + e] = (e == 0 ? tp0 : tp1);
-                FA_SYNC();
+                FA_SYNC_LDS();
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int idx = v2 + (NN / R) * i;         // element of the next stage's factor
@@ -984,7 +1005,7 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
 #pragma unroll
                     for (int i = 0; i < R; i++) { a21[i] = na[i]; b21[i] = nb[i]; }
                 }
-                if (DB) parity ^= 1;
+                if (DB && !FA_MULTI_PAIR2) parity ^= 1;
             }
             MultiRun<N0, STAGES, R, BF, DB, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity, ltail,
                                                         lwexp);
@@ -993,8 +1014,8 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
             const int n_out = n_stage >> 1;
             double m2 = 0.0;
             for (int e = 0; e < 2; e++) {
-                cplx *stg = DB ? lds + (size_t)parity * kBufElems : lds;
-                if (!DB) FA_SYNC();
+                cplx *stg = FA_MULTI_PAIR2 ? lds + (size_t)e * kBufElems : (DB ? lds + (size_t)parity * kBufElems : lds);
+                if (!DB && !FA_MULTI_PAIR2) FA_SYNC_LDS();
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int idx = v + (N / R) * i;
@@ -1011,7 +1032,7 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
                     const int rot = (idx + c) & (N - 1);
                     stg[(size_t)c * N + rot] = val;
                 }
-                FA_SYNC();
+                FA_SYNC_LDS();
                 const long long Pg0 = mat0 >> (S + 1);
                 const long long nvalid = (n_out - Pg0 < PAIRS) ? n_out - Pg0 : PAIRS;
                 const int total = (int)nvalid * N;
@@ -1021,10 +1042,10 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
                     const int rot = (i3 + c3) & (N - 1);
                     out0[m] = stg[(size_t)c3 * N + rot];
                 }
-                if (DB) parity ^= 1;
+                if (DB && !FA_MULTI_PAIR2) parity ^= 1;
             }
             if (act) fa_atomic_max_u64(&mx[c], dbits(m2));
-            FA_SYNC();
+            FA_SYNC_LDS();
             if (v == 0 && act) {
                 const double mm = bitsd(mx[c]);
                 int a = 0;
@@ -1054,7 +1075,7 @@ template <int N0, int STAGES, int R, int BF, bool DB> FA_DEV void body_multi_fft
     constexpr int P0 = BF << (STAGES - 1);          // pairs of stage 0
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
-    cplx *tails = lds + (size_t)(DB ? 2 : 1) * T * R;   // [stage][pair][2]
+    cplx *tails = lds + (size_t)((DB || FA_MULTI_PAIR2) ? 2 : 1) * T * R;   // [stage][pair][2]
     unsigned long long *mx = (unsigned long long *)(tails + (size_t)2 * 2 * P0);
     const int tid = FA_TID;
     const long long blk = FA_BID;
@@ -1074,35 +1095,37 @@ template <int N0, int STAGES, int R, int BF, bool DB> FA_DEV void body_multi_fft
             twp[s] = twl + off;
             off += len;
         }
-        FA_SYNC();
+        FA_SYNC_LDS();
     }
     cplx a11[R], a21[R], b11[R], b21[R];
     // ---- stage 0: factors from HBM -----------------------------------------------------------
+    // N0 = 2d: registers i < R/2 hold coefficients, register R/2 of the lanes with v == 0 the constant
+    // term, everything else is zero padding.  All loads are unconditional (clamped for the inactive
+    // tail of the grid) and issued back to back; scales and masks are applied afterwards.
     {
         const int c = tid % P0, v = tid / P0;
         const long long mA = mat0 + 2 * c, mB = mA + 1;
         const bool act = mB < n_in;
-        const int d = L.d;
-        const double sA = act ? L.scale_in[mA] : 0.0, sB = act ? L.scale_in[mB] : 0.0;
+        const long long mAc = act ? mA : 0, mBc = act ? mB : 0;
+        const size_t d = (size_t)L.d;
+        const cplx *pA0 = L.body_in + (size_t)mAc * d, *pA1 = pA0 + L.plane;
+        const cplx *pB0 = L.body_in + (size_t)mBc * d, *pB1 = pB0 + L.plane;
 #pragma unroll
-        for (int i = 0; i < R; i++) {
+        for (int i = 0; i < R / 2; i++) {
             const int idx = v + (N0 / R) * i;
-            cplx x0 = cmake(0.0, 0.0), x1 = x0, y0 = x0, y1 = x0;
-            if (act) {
-                if (idx < d) {
-                    x0 = L.body_in[(size_t)mA * d + idx] * sA;
-                    x1 = L.body_in[L.plane + (size_t)mA * d + idx] * sA;
-                    y0 = L.body_in[(size_t)mB * d + idx] * sB;
-                    y1 = L.body_in[L.plane + (size_t)mB * d + idx] * sB;
-                } else if (idx == d) {
-                    x0 = L.tail_in[mA] * sA;
-                    x1 = L.tail_in[(size_t)n_in + mA] * sA;
-                    y0 = L.tail_in[mB] * sB;
-                    y1 = L.tail_in[(size_t)n_in + mB] * sB;
-                }
-            }
-            a11[i] = x0; a21[i] = x1; b11[i] = y0; b21[i] = y1;
+            a11[i] = pA0[idx]; a21[i] = pA1[idx]; b11[i] = pB0[idx]; b21[i] = pB1[idx];
         }
+        const cplx tA0 = L.tail_in[mAc], tA1 = L.tail_in[(size_t)n_in + mAc];
+        const cplx tB0 = L.tail_in[mBc], tB1 = L.tail_in[(size_t)n_in + mBc];
+        const double sA = act ? L.scale_in[mAc] : 0.0, sB = act ? L.scale_in[mBc] : 0.0;
+#pragma unroll
+        for (int i = 0; i < R / 2; i++) {
+            a11[i] = a11[i] * sA; a21[i] = a21[i] * sA; b11[i] = b11[i] * sB; b21[i] = b21[i] * sB;
+        }
+        const double tA = (v == 0) ? sA : 0.0, tB = (v == 0) ? sB : 0.0;
+        a11[R / 2] = tA0 * tA; a21[R / 2] = tA1 * tA; b11[R / 2] = tB0 * tB; b21[R / 2] = tB1 * tB;
+#pragma unroll
+        for (int i = R / 2 + 1; i < R; i++) a11[i] = a21[i] = b11[i] = b21[i] = cmake(0.0, 0.0);
     }
     // ---- stages ---------------------------------------------------------------------------------
     multi_stage_run<N0, STAGES, R, BF, DB, 0>(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp);
@@ -1126,7 +1149,7 @@ template <int DEG, int SPT, int STAGES, int R, int BF, bool DB> FA_DEV void body
     static_assert(T == 2 * P0, "lanes = matrices of the block");
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
-    cplx *tails = lds + (size_t)(DB ? 2 : 1) * T * R;
+    cplx *tails = lds + (size_t)((DB || FA_MULTI_PAIR2) ? 2 : 1) * T * R;
     unsigned long long *mx = (unsigned long long *)(tails + (size_t)2 * 2 * P0);
     cplx *twl = (cplx *)(mx + ((BF + 1) & ~1));
     constexpr int kTwTotal = N0 * ((1 << STAGES) - 1);
@@ -1192,10 +1215,10 @@ template <int DEG, int SPT, int STAGES, int R, int BF, bool DB> FA_DEV void body
     cplx a11[R], a21[R], b11[R], b21[R];
     const int c = tid % P0, v = tid / P0;     // stage-0 lane: pair c, elements v + 2 i
     for (int e = 0; e < 2; e++) {
-        FA_SYNC();
+        FA_SYNC_LDS();
 #pragma unroll
         for (int k2 = 0; k2 < d; k2++) lds[(size_t)tid * d + ((k2 + tid) & (d - 1))] = acc[2 * e][k2] * sc;
-        FA_SYNC();
+        FA_SYNC_LDS();
         cplx xa[R], xb[R];
 #pragma unroll
         for (int i = 0; i < R; i++) {
@@ -1218,7 +1241,7 @@ template <int DEG, int SPT, int STAGES, int R, int BF, bool DB> FA_DEV void body
             for (int i = 0; i < R; i++) { a21[i] = xa[i]; b21[i] = xb[i]; }
         }
     }
-    FA_SYNC();   // staging fully read before the first transform writes the buffer (DB: buffer 0)
+    FA_SYNC_LDS();   // staging fully read before the first transform writes the buffer (DB: buffer 0)
     int parity = 0;
     MultiRun<N0, STAGES, R, BF, DB, 0>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity, ltail, lwexp);
 }
@@ -1249,7 +1272,42 @@ struct BigLevel {
     // first split level with N1 = 4 and N = 2d: no column kernel -- the row kernel forms the length-4
     // column transform itself, Y[k1][n2] = x[n2] + i^(-k1) x[N2 + n2] (+ (-1)^k1 tail at n2 = 0)
     int y_direct;
+    int stagger;     // row kernel: start delay of the second half of the grid, units of ~1024 clocks (0: none)
+    // diagnostic builds (-DFNFT_AMD_STAMPS) only: per-wave s_memtime stamps of the row kernel's phases,
+    // 16 slots per wave, or NULL
+    unsigned long long *stamps;
 };
+
+#ifdef FNFT_AMD_STAMPS
+#define FA_STAMP(ptr, slot)                                                                              \
+    do {                                                                                                 \
+        if (ptr) {                                                                                       \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                  \
+            if ((FA_TID & 63) == 0) (ptr)[((size_t)FA_BID * (FA_BDIM / 64) + FA_TID / 64) * 16 + (slot)] = t_; \
+        }                                                                                                \
+    } while (0)
+#else
+#define FA_STAMP(ptr, slot) do { } while (0)
+#endif
+
+// Element (row, n2) of one polynomial's Y/Z scratch block of `rows` x N2 elements.  The block is stored
+// in tiles of FA_YZ_TILE consecutive n2: [n2 tile][row][n2 in tile].  A column kernel that owns BC
+// consecutive n2 for every row then streams a contiguous region (rows x 1 KB per tile) instead of
+// touching `rows` places 16*N2 bytes apart, and a row kernel still moves whole 1 KB pieces per wave
+// instruction (64 consecutive n2).  FA_YZ_TILE = 0: plain [row][n2].
+#ifndef FA_YZ_TILE
+#define FA_YZ_TILE 64
+#endif
+FA_HD size_t yz_index(int rows, int N2, int row, int n2)
+{
+#if FA_YZ_TILE > 0
+    (void)N2;
+    return ((size_t)(n2 / FA_YZ_TILE) * (size_t)rows + (size_t)row) * FA_YZ_TILE + (size_t)(n2 % FA_YZ_TILE);
+#else
+    (void)rows;
+    return (size_t)row * (size_t)N2 + (size_t)n2;
+#endif
+}
 
 // column step of the forward transform of every input polynomial of the level
 //   grid.x = N2/BC tiles, grid.y = 4*n_in polynomials
@@ -1284,7 +1342,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLeve
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int k1 = v + (N1 / R) * i;
-        dst[(size_t)k1 * N2 + n2] = x[i];
+        dst[yz_index(N1, N2, k1, n2)] = x[i];
     }
 }
 
@@ -1353,17 +1411,22 @@ template <int N2, int R> struct MidIO {
             return;
         }
         const cplx *src;
+        int rows, row;
         if (G.y_split) {
             const cplx *half = (k1 & 1) ? G.Y : G.Zprev;
-            src = half + (pi * (size_t)(G.N1 / 2) + (size_t)(k1 >> 1)) * N2;
+            rows = G.N1 / 2;
+            row = k1 >> 1;
+            src = half + pi * (size_t)rows * N2;
         } else {
-            src = G.Y + (pi * (size_t)G.N1 + k1) * N2;
+            rows = G.N1;
+            row = k1;
+            src = G.Y + pi * (size_t)rows * N2;
         }
         const cplx base = wbase * sc[which];
 #pragma unroll
-        for (int i = 0; i < R; i++) x[i] = src[v + (N2 / R) * i] * twiddle(base, i);
+        for (int i = 0; i < R; i++) x[i] = src[yz_index(rows, N2, row, v + (N2 / R) * i)] * twiddle(base, i);
     }
-    FA_DEV int dbg() const { return G.L.dbg; }
+    FA_DEV int dbg() const { return FA_DBG(G.L.dbg); }
     FA_DEV void sink(cplx (&x)[R], cplx (&y)[R])
     {
         double s = 0.0;
@@ -1382,10 +1445,10 @@ template <int N2, int R> struct MidIO {
     FA_DEV void store(int e, cplx (&x)[R], int v, int, cplx *, int &)
     {
         const int n_out = G.L.n_in / 2;
-        cplx *dst = G.Z + ((size_t)((size_t)e * n_out + P) * G.N1 + k1) * N2;
+        cplx *dst = G.Z + (size_t)((size_t)e * n_out + P) * G.N1 * N2;
         const cplx base = wbase * (1.0 / (double)N2);
 #pragma unroll
-        for (int i = 0; i < R; i++) dst[v + (N2 / R) * i] = x[i] * cconj(twiddle(base, i));
+        for (int i = 0; i < R; i++) dst[yz_index(G.N1, N2, k1, v + (N2 / R) * i)] = x[i] * cconj(twiddle(base, i));
     }
 };
 
@@ -1398,6 +1461,166 @@ template <int N2, int R, int NE> FA_DEV void body_mid(const BigLevel &G)
     // the 2048-entry table stays in L2: three reads per butterfly, other powers by multiplication
     if (NE == 4) pair_product_core<N2, R, 1, true, true>(io, lds, tw);
     else pair_product_core_sym<N2, R, 1, true, true>(io, lds, tw, G.L.kappa);
+}
+
+// Row step of the symmetric form, written for memory-level parallelism: the row pointers of the four
+// input polynomials are formed without branches, all 4*R (DIRECT: 2 x 4*R) 16-byte loads of the lane
+// are issued back to back before anything consumes them (the generic IO object above branches per
+// polynomial on the level's flags, which made every polynomial its own memory round trip), the
+// transforms run in pairs (fft_wg2: a11 with a21, b11 with b21, c11 with c21), and every barrier is
+// an LDS-only one, so the stores of c11 stay in flight under the tail of the c21 transform.
+//   DIRECT: first split level with N1 = 4 and N = 2d -- the row kernel forms the length-4 column
+//   transform itself, Y[k1][n2] = x[n2] + (-i)^k1 x[N2 + n2]  (+ (-1)^k1 * tail at n2 = 0).
+template <int N2, int R, bool DIRECT> FA_DEV void body_mid_sym(const BigLevel &G)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int v = FA_TID;
+    const int n_in = L.n_in, n_out = n_in / 2;
+    long long P;
+    int k1;
+    if (DIRECT && (n_out % 8) == 0) {
+        // the four k1 of a pair read the same two coefficient rows: keep them on one XCD (workgroups
+        // b and b + 8 share one), so the rows come out of that XCD's L2 three times out of four
+        const int q = FA_BID / 8, x = FA_BID % 8;
+        k1 = q % 4;
+        P = (long long)(q / 4) * 8 + x;
+    } else {
+        P = FA_BID / G.N1;
+        k1 = FA_BID % G.N1;
+    }
+    const long long mA = 2 * P, mB = 2 * P + 1;
+    cplx a11[R], a21[R], b11[R], b21[R];
+    // One level is one round of resident workgroups (two per CU), which all start together and then
+    // sit in the same phase -- everybody loading (HBM saturated, vector units idle), then everybody
+    // transforming (vector units saturated, HBM idle).  Holding back the second half of the grid -- the
+    // second workgroup of every CU -- by about one load phase puts the two halves in complementary phases.
+    fa_stagger(G.stagger, FA_BID >= FA_GDIM / 2);
+    FA_STAMP(G.stamps, 0);
+    // ---- loads ------------------------------------------------------------------------------------
+    if constexpr (DIRECT) {
+        const size_t d = (size_t)L.d;
+        const cplx *pA0 = L.body_in + (size_t)mA * d, *pA1 = L.body_in + L.plane + (size_t)mA * d;
+        const cplx *pB0 = L.body_in + (size_t)mB * d, *pB1 = L.body_in + L.plane + (size_t)mB * d;
+        cplx h0[R], h1[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) { a11[i] = pA0[v + (N2 / R) * i]; a21[i] = pA1[v + (N2 / R) * i]; }
+#pragma unroll
+        for (int i = 0; i < R; i++) { h0[i] = pA0[N2 + v + (N2 / R) * i]; h1[i] = pA1[N2 + v + (N2 / R) * i]; }
+#pragma unroll
+        for (int i = 0; i < R; i++) { b11[i] = pB0[v + (N2 / R) * i]; b21[i] = pB1[v + (N2 / R) * i]; }
+        const cplx tA0 = L.tail_in[mA], tA1 = L.tail_in[(size_t)n_in + mA];
+        const cplx tB0 = L.tail_in[mB], tB1 = L.tail_in[(size_t)n_in + mB];
+        const int kq = k1 & 3;
+        auto rot = [kq](cplx z) -> cplx {   // z * (-i)^k1
+            return kq == 0 ? z : (kq == 1 ? cmake(z.y, -z.x) : (kq == 2 ? cmake(-z.x, -z.y) : cmake(-z.y, z.x)));
+        };
+        const double sg = (k1 & 1) ? -1.0 : 1.0;
+#pragma unroll
+        for (int i = 0; i < R; i++) { a11[i] = a11[i] + rot(h0[i]); a21[i] = a21[i] + rot(h1[i]); }
+#pragma unroll
+        for (int i = 0; i < R; i++) { h0[i] = pB0[N2 + v + (N2 / R) * i]; h1[i] = pB1[N2 + v + (N2 / R) * i]; }
+#pragma unroll
+        for (int i = 0; i < R; i++) { b11[i] = b11[i] + rot(h0[i]); b21[i] = b21[i] + rot(h1[i]); }
+        if (v == 0) {   // n2 = 0 is element 0 of lane 0
+            a11[0] = a11[0] + tA0 * sg; a21[0] = a21[0] + tA1 * sg;
+            b11[0] = b11[0] + tB0 * sg; b21[0] = b21[0] + tB1 * sg;
+        }
+    } else {
+        const bool split = G.y_split != 0;
+        const int rows = split ? G.N1 / 2 : G.N1;
+        const int row = split ? (k1 >> 1) : k1;
+        const cplx *base = split ? ((k1 & 1) ? G.Y : G.Zprev) : G.Y;
+        const size_t blk = (size_t)rows * N2;
+        const cplx *pA0 = base + (size_t)mA * blk, *pA1 = base + ((size_t)n_in + mA) * blk;
+        const cplx *pB0 = base + (size_t)mB * blk, *pB1 = base + ((size_t)n_in + mB) * blk;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const size_t o = yz_index(rows, N2, row, v + (N2 / R) * i);
+            a11[i] = pA0[o]; a21[i] = pA1[o];
+        }
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const size_t o = yz_index(rows, N2, row, v + (N2 / R) * i);
+            b11[i] = pB0[o]; b21[i] = pB1[o];
+        }
+    }
+    FA_STAMP(G.stamps, 1);
+    // ---- bookkeeping of the level (once per pair) and the factors every polynomial shares ------------
+    if (k1 == 0 && v == 0) {
+        L.wexp_out[P] = level_in_wexp(L, mA) + level_in_wexp(L, mB);
+        L.max2_out[P] = 0ull;
+    }
+    const bool rescale = DIRECT || G.y_unscaled;
+    const double scA = rescale ? level_in_scale(L, mA) : 1.0, scB = rescale ? level_in_scale(L, mB) : 1.0;
+    // w_N^{k1 n2}, n2 = v + (N2/R) i: per-lane w^{k1 v} times workgroup-uniform w^{k1 (N2/R) i}
+    const cplx wbase = big_twiddle(G.btw, (unsigned)k1 * (unsigned)v);
+    cplx wu[R];
+    wu[0] = cmake(1.0, 0.0);
+#pragma unroll
+    for (int i = 1; i < R; i++) {
+        const cplx w = big_twiddle(G.btw, (unsigned)k1 * (unsigned)((N2 / R) * i));
+        wu[i] = cmake(fa_uniform(w.x), fa_uniform(w.y));
+    }
+    // the left factor's rows are the first half of the loads: its transforms start while the right
+    // factor's rows are still arriving
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx wA = ((i == 0) ? wbase : wbase * wu[i]) * scA;
+        a11[i] = a11[i] * wA; a21[i] = a21[i] * wA;
+    }
+    // ---- transforms and product -----------------------------------------------------------------------
+    const cplx *tw = G.tw2;
+    FA_STAMP(G.stamps, 2);
+    fft_wg2<N2, R, 1, -1, true>(a11, a21, lds, v, 0, tw);
+    FA_STAMP(G.stamps, 3);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx wB = ((i == 0) ? wbase : wbase * wu[i]) * scB;
+        b11[i] = b11[i] * wB; b21[i] = b21[i] * wB;
+    }
+    fft_wg2<N2, R, 1, -1, true>(b11, b21, lds, v, 0, tw);
+    FA_STAMP(G.stamps, 4);
+    const double mk = (double)(-L.kappa);
+    const long long N = (long long)G.N1 * N2;
+    if (N == 2 * (long long)L.d) {
+        // g = exp(-2 pi i d k/N) = (-1)^k, k = k1 + N1*k2: the parity of k1 (N1 is even)
+        const double g = (k1 & 1) ? -1.0 : 1.0;
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const cplx gb = b21[i] * g;
+            const cplx c11 = cfma(cconj(a21[i]) * mk, gb, a11[i] * b11[i]);   // A11 B11 - k g A21* B21
+            const cplx c21 = cfma(cconj(a11[i]), gb, a21[i] * b11[i]);        // A21 B11 +   g A11* B21
+            b11[i] = c11;
+            b21[i] = c21;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const long long kbin = (long long)k1 + (long long)G.N1 * (v + (N2 / R) * i);
+            const cplx g = big_twiddle(G.btw, (unsigned)(((long long)L.d * kbin) % N));
+            const cplx gb = g * b21[i];
+            const cplx c11 = cfma(cconj(a21[i]) * mk, gb, a11[i] * b11[i]);
+            const cplx c21 = cfma(cconj(a11[i]), gb, a21[i] * b11[i]);
+            b11[i] = c11;
+            b21[i] = c21;
+        }
+    }
+    FA_STAMP(G.stamps, 5);
+    fft_wg2<N2, R, 1, +1, true>(b11, b21, lds, v, 0, tw);
+    FA_STAMP(G.stamps, 6);
+    // ---- stores: conj twiddle and 1/N2 -------------------------------------------------------------------
+    cplx *d0 = G.Z + (size_t)P * G.N1 * N2, *d1 = G.Z + ((size_t)n_out + P) * G.N1 * N2;
+    const cplx wb = wbase * (1.0 / (double)N2);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx w = cconj((i == 0) ? wb : wb * wu[i]);
+        const size_t o = yz_index(G.N1, N2, k1, v + (N2 / R) * i);
+        d0[o] = b11[i] * w;
+        d1[o] = b21[i] * w;
+    }
+    FA_STAMP(G.stamps, 7);
 }
 
 // column step of the inverse transform of every output polynomial
@@ -1421,7 +1644,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int k1 = v + (N1 / R) * i;
-        x[i] = src[(size_t)k1 * N2 + n2];   // conj twiddle already applied by the row kernel
+        x[i] = src[yz_index(N1, N2, k1, n2)];   // conj twiddle already applied by the row kernel
     }
     int parity = 0;
     fft_wg<N1, R, BC, +1, DB, true>(x, lds, v, c, G.tw1, parity);
@@ -1493,7 +1716,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int k1 = v + (N1 / R) * i;
-        x[i] = src[(size_t)k1 * N2 + n2];   // conj twiddle already applied by the row kernel
+        x[i] = src[yz_index(N1, N2, k1, n2)];   // conj twiddle already applied by the row kernel
     }
     int parity = 0;
     {
@@ -1556,7 +1779,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
 #pragma unroll
     for (int i = 0; i < 2 * R; i++) {
         const int k1 = v + (N1 / R) * i;   // (2N1)/(2R) = N1/R
-        dst[(size_t)k1 * N2 + n2] = x[i];  // twiddle applied by the next level's row kernel
+        dst[yz_index(2 * N1, N2, k1, n2)] = x[i];  // twiddle applied by the next level's row kernel
     }
 }
 
@@ -1583,7 +1806,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
     const cplx *src = G.Z + (size_t)poly * N1 * N2;
     cplx x[R];
 #pragma unroll
-    for (int i = 0; i < R; i++) x[i] = src[(size_t)(v + (N1 / R) * i) * N2 + n2];
+    for (int i = 0; i < R; i++) x[i] = src[yz_index(N1, N2, v + (N1 / R) * i, n2)];
     int parity = 0;
     fft_wg<N1, R, BC, +1, DB, true>(x, lds, v, c, G.tw1, parity);
     const double inv = 1.0 / (double)N1;
@@ -1655,7 +1878,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int j = v + (N1 / R) * i;
-        dst[(size_t)j * N2 + n2] = x[i] - tpc;
+        dst[yz_index(N1, N2, j, n2)] = x[i] - tpc;
     }
 }
 
@@ -1860,7 +2083,7 @@ template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_f
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int k1 = v + (N1 / R) * i;
-        dst[(size_t)k1 * C.N2 + n2] = x[i];
+        dst[yz_index(N1, C.N2, k1, n2)] = x[i];
     }
 }
 
@@ -1886,9 +2109,8 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
 #pragma unroll
         for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i];
     } else {
-        const cplx *vs = C.Vbuf + (size_t)k1 * N2;
 #pragma unroll
-        for (int i = 0; i < R; i++) vv[i] = vs[v + (N2 / R) * i] * tw[i];
+        for (int i = 0; i < R; i++) vv[i] = C.Vbuf[yz_index(C.N1, N2, k1, v + (N2 / R) * i)] * tw[i];
         fft_wg<N2, R, 1, -1, DB, true>(vv, lds, v, 0, C.tw2, parity);
         if (C.v_mode == 1 && FA_BID_Y == 0) {
             cplx *vd = C.VS + (size_t)k1 * N2;
@@ -1901,16 +2123,16 @@ template <int N2, int R, bool DB> FA_DEV void body_chirp_rows(const ChirpParams 
     const int job0 = FA_BID_Y * C.jobs_per_group;
     const int job1 = (job0 + C.jobs_per_group < njobs) ? job0 + C.jobs_per_group : njobs;
     for (int job = job0; job < job1; job++) {
-        cplx *ys = C.Ybuf + (size_t)job * Lc + (size_t)k1 * N2;
+        cplx *ys = C.Ybuf + (size_t)job * Lc;
         cplx y[R];
 #pragma unroll
-        for (int i = 0; i < R; i++) y[i] = ys[v + (N2 / R) * i] * tw[i];
+        for (int i = 0; i < R; i++) y[i] = ys[yz_index(C.N1, N2, k1, v + (N2 / R) * i)] * tw[i];
         fft_wg<N2, R, 1, -1, DB, true>(y, lds, v, 0, C.tw2, parity);
 #pragma unroll
         for (int i = 0; i < R; i++) y[i] = y[i] * vv[i];
         fft_wg<N2, R, 1, +1, DB, true>(y, lds, v, 0, C.tw2, parity);
 #pragma unroll
-        for (int i = 0; i < R; i++) ys[v + (N2 / R) * i] = (y[i] * inv) * cconj(tw[i]);
+        for (int i = 0; i < R; i++) ys[yz_index(C.N1, N2, k1, v + (N2 / R) * i)] = (y[i] * inv) * cconj(tw[i]);
     }
 }
 
@@ -1940,7 +2162,7 @@ template <int N1, int R, int BC, bool DB, bool DFT, bool KDV> FA_DEV void body_c
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const int k1 = v + (N1 / R) * i;
-            x[i] = src[(size_t)k1 * C.N2 + n2];   // conj twiddle applied by the row kernel
+            x[i] = src[yz_index(N1, C.N2, k1, n2)];   // conj twiddle applied by the row kernel
         }
         fft_wg<N1, R, BC, +1, DB, true>(x, lds, v, c, C.tw1, parity);
 #pragma unroll

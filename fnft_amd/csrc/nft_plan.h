@@ -163,7 +163,10 @@ public:
     LeafParams leaf_lp;
     int ne = 4;              // stored entries per matrix in the current tree run
     int kappa_run = 1;
-    int dbg_flags = 0;       // timing ablation, set from FNFT_AMD_DBG by the HIP back end (diagnostics only)
+    unsigned long long *dbg_stamps = nullptr;   // -DFNFT_AMD_STAMPS builds: 16 u64 per wave of the row kernel
+    int stamp_level = -1;                        // split level (0 = first) whose row kernel is stamped
+    int tune_stagger = 0;    // row kernel start delay of the second half of a one-round grid (BigLevel::stagger)
+    int dbg_flags = 0;       // timing ablation: only builds with -DFNFT_AMD_ABLATION ever set it (hip_backend.hip)
 
     NftPlan(BE &be_, size_t D_, size_t M_, size_t batch_, int akns_disc_, int deg0_)
         : be(be_), D(D_), M(M_), batch(batch_), akns_disc(akns_disc_), deg0(deg0_)
@@ -279,7 +282,7 @@ public:
         be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
         be.free(chY); be.free(chV); be.free(chH); be.free(chVS); be.free(tm_out); be.free(twtab); be.free(twlo);
         be.free(prog_bfrac); be.free(prog_mw); be.free(prog_ptr); be.free(prog_fac);
-        be.free(rneg);
+        be.free(rneg); be.free(dbg_stamps);
         be.free(qpre); be.free(rsX); be.free(rsX12); be.free(rsQ12); be.free(rsY); be.free(rsV);
     }
 
@@ -457,6 +460,7 @@ public:
         int zcur = 0;
         bool in_pending = false;   // previous level was split: its rescale is still pending
         int mcur = 0;
+        int split_idx = 0;
         while (n / batch > 1) {
             TreeLevel L;
             L.body_in = body[cur]; L.tail_in = tail[cur]; L.scale_in = scale[cur];
@@ -528,6 +532,9 @@ public:
                 // first split level: a length-4 column transform of two non-zero rows is done by the row
                 // kernel on the fly (saves the column launch and its 32 + 64 MB)
                 G.y_direct = (use_direct4 && !y_from_bridge && G.N1 == 4 && N == 2 * d && dbg_flags == 0) ? 1 : 0;
+                G.stagger = (n / 2 * (size_t)G.N1 == 512) ? tune_stagger : 0;   // exactly one round of workgroups
+                G.stamps = (dbg_stamps && split_idx == stamp_level) ? dbg_stamps : nullptr;
+                split_idx++;
                 ok = true;
                 if (!y_from_bridge && !G.y_direct) ok = dispatch_col_fwd(be, G);
                 if (ok) run_mid(be, G);

@@ -217,8 +217,18 @@ FNFT_INT fnft__nse_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q, cons
 
 typedef struct fnft_amd_plan fnft_amd_plan_t;
 
+/* Device rule.  Every host-pointer entry point of sections 1, 2 and 4 (fnft_nsev, fnft_kdvv,
+ * fnft__*_fscatter, fnft__poly_fmult*, fnft__poly_chirpz) computes on the calling thread's CURRENT
+ * HIP device -- the one hipSetDevice() / torch.cuda.set_device() selected, device 0 if nothing was
+ * selected -- and leaves the current device unchanged; cached plans are keyed by that device.  In a
+ * one-process-per-GPU job each rank therefore selects its GPU once (LOCAL_RANK) and calls the
+ * drop-in as usual.  A device-resident plan lives on the `device` given at creation; plan calls
+ * may be made with any current device and restore it before they return. */
+
 /* Number of HIP devices visible; <0 on HIP failure. */
 int fnft_amd_device_count(void);
+/* The calling thread's current HIP device (what the host-pointer entry points will use); <0: none. */
+int fnft_amd_current_device(void);
 /* Last HIP error text of the calling thread ("" if none). */
 const char *fnft_amd_last_error(void);
 
@@ -235,6 +245,8 @@ FNFT_INT fnft_amd_plan_create_sub(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT
 void fnft_amd_plan_destroy(fnft_amd_plan_t *plan);
 /* Bytes of HBM the plan holds. */
 FNFT_UINT fnft_amd_plan_workspace_bytes(const fnft_amd_plan_t *plan);
+/* Device the plan's workspace lives on (-1 for NULL). */
+int fnft_amd_plan_device(const fnft_amd_plan_t *plan);
 
 /* Continuous spectrum of batch signals, everything resident in HBM:
  *   d_q:        batch*D complex128 (device), signal b at d_q + b*D

@@ -63,6 +63,8 @@ def walk_stages(src, arr_pat=r"error_bounds\w*", harness="nsev_testcases_test_fn
     env = {"D": None, "DN": None}
     arrays = {}
     rich = 0
+    dsub = None    # opts.Dsub as last assigned (None: the default 0 = automatic)
+    niter = None   # opts.niter as last assigned (None: the default 10)
     stages = []
     inf = float("inf")
 
@@ -81,6 +83,8 @@ def walk_stages(src, arr_pat=r"error_bounds\w*", harness="nsev_testcases_test_fn
         r"|(?P<dop>\bD\s*(?P<do>[*/+-])=\s*(?P<dval>[^;]+);)"
         r"|(?P<dset>\bD\s*=\s*(?P<dsv>[^;=]+);)"
         r"|(?P<rich>opts\.richardson_extrapolation_flag\s*=\s*(?P<rv>\d)\s*;)"
+        r"|(?P<dsub>opts\.Dsub\s*=\s*(?P<dsv2>[^;]+);)"
+        r"|(?P<niter>opts\.niter\s*=\s*(?P<nv>[^;]+);)"
         r"|(?P<call>" + harness + r"\s*\(\s*tc\s*,\s*(?P<cd>[^,]+),\s*(?P<ca>\w+)\s*,)",
         flags=re.S)
     for m in tok.finditer(body):
@@ -105,10 +109,15 @@ def walk_stages(src, arr_pat=r"error_bounds\w*", harness="nsev_testcases_test_fn
             env["D"] = int(num(m.group("dsv")))
         elif m.group("rich"):
             rich = int(m.group("rv"))
+        elif m.group("dsub"):
+            dsub = int(num(m.group("dsv2")))
+        elif m.group("niter"):
+            niter = int(num(m.group("nv")))
         elif m.group("call"):
             stages.append({"D": int(num(m.group("cd"))), "richardson": rich,
                            "bounds": list(arrays[m.group("ca")][:3]),
-                           "bounds_ds": list(arrays[m.group("ca")][3:6])})
+                           "bounds_ds": list(arrays[m.group("ca")][3:6]),
+                           "Dsub": dsub, "niter": niter})
     return stages
 
 
