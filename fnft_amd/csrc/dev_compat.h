@@ -40,6 +40,24 @@ FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
         atomicMax(p, cv.u);
     }
 }
+// max over the wave of the high dword of a non-negative double, then ONE atomicMax per wave
+FA_DEV void fa_wave_atomic_max_hi32(unsigned *p, double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(p, (unsigned)__double2hiint(v));
+}
+// max of 64 consecutive u32 (one per lane, reduced across the wave); every lane of the wave must be active
+FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
+{
+    unsigned x = p[threadIdx.x & 63];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned y = (unsigned)__shfl_xor((int)x, off, 64);
+        x = y > x ? y : x;
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+}
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 // start delay of part of a grid: n sleep periods of ~1024 clocks for the waves that are `late`
@@ -89,6 +107,20 @@ FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
     union { double d; unsigned long long u; } cv;
     cv.d = v;
     fa_atomic_max_u64(p, cv.u);
+}
+FA_DEV void fa_wave_atomic_max_hi32(unsigned *p, double v)
+{
+    union { double d; unsigned long long u; } cv;
+    cv.d = v;
+    const unsigned hi = (unsigned)(cv.u >> 32);
+    unsigned cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (cur < hi && !__atomic_compare_exchange_n(p, &cur, hi, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
+{
+    unsigned x = 0u;
+    for (int s = 0; s < 64; s++) x = p[s] > x ? p[s] : x;
+    return x;
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }

@@ -41,8 +41,8 @@ struct TreeLevel {
     cplx *body_out;
     cplx *tail_out;
     double *scale_out;
-    unsigned long long *max2_out;  // per output matrix: bits of max |coef|^2 (large path)
-    const unsigned long long *max2_in;  // per input matrix, valid when in_pending
+    unsigned *max2_out;            // per output matrix, kMax2Slots slots: high dword of max |coef|^2 (split levels)
+    const unsigned *max2_in;       // per input matrix, valid when in_pending
     int in_pending;                // inputs come from a split level whose rescale is still pending:
                                    // scale = 2^-a(max2_in), exponent = wexp_in + a(max2_in)
     const int *wexp_in;            // per input matrix: power-of-two exponent taken out so far
@@ -85,20 +85,36 @@ FA_HD double bitsd(unsigned long long u)
     return cv.d;
 }
 
-FA_HD int exponent_of_max2(unsigned long long bits)
+// The running maximum of |coef|^2 of a product matrix of a split level is kept as the HIGH dword of
+// the double (positive doubles order like their high dwords, and only the exponent field is used), in
+// kMax2Slots slots per matrix: the waves of the column kernels spread their atomicMax over the slots
+// (the top levels have one to four matrices, and thousands of atomics on one address serialise at the
+// memory side); readers take the maximum over the slots.
+constexpr int kMax2Slots = 64;
+FA_HD int exponent_of_max2(unsigned hi)
 {
-    const double m2 = bitsd(bits);
-    return (m2 > 0.0 && m2 < 1.0e300) ? half_exponent(m2) : 0;
+    // m2 > 0 and m2 < 1e300 (high dword 0x7E37E43C): floor(log2(sqrt(m2))) from the exponent field
+    if (hi == 0u || hi >= 0x7E37E43Cu) return 0;
+    const int e = (int)((hi >> 20) & 0x7ffu) - 1023;
+    return e >> 1;
 }
-// pending scale / accumulated exponent of input matrix `mat` of a level (see TreeLevel::in_pending)
+FA_DEV int max2_slot() { return (FA_BID_Y * 5 + FA_BID * (FA_BDIM / 64) + FA_TID / 64) & (kMax2Slots - 1); }
+// exponent still to be taken out of input matrix `mat` of a level (see TreeLevel::in_pending).
+// WAVE-UNIFORM call only: every lane of the wave active, same `mat` (the slots are read one per lane
+// and reduced across the wave).
+FA_DEV int level_in_pending_exp(const TreeLevel &L, long long mat)
+{
+    return L.in_pending ? exponent_of_max2(fa_slots_max_u32(L.max2_in + (size_t)mat * kMax2Slots)) : 0;
+}
+// pending scale / accumulated exponent of input matrix `mat` of a level (wave-uniform calls only)
 FA_DEV double level_in_scale(const TreeLevel &L, long long mat)
 {
     if (!L.in_pending) return L.scale_in[mat];
-    return pow2i(-exponent_of_max2(L.max2_in[mat]));
+    return pow2i(-level_in_pending_exp(L, mat));
 }
 FA_DEV int level_in_wexp(const TreeLevel &L, long long mat)
 {
-    return L.wexp_in[mat] + (L.in_pending ? exponent_of_max2(L.max2_in[mat]) : 0);
+    return L.wexp_in[mat] + level_in_pending_exp(L, mat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1282,7 +1298,7 @@ struct BigLevel {
 #define FA_STAMP(ptr, slot)                                                                              \
     do {                                                                                                 \
         if (ptr) {                                                                                       \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();   /* 100 MHz, chip-wide */                                  \
             if ((FA_TID & 63) == 0) (ptr)[((size_t)FA_BID * (FA_BDIM / 64) + FA_TID / 64) * 16 + (slot)] = t_; \
         }                                                                                                \
     } while (0)
@@ -1371,10 +1387,9 @@ template <int N2, int R> struct MidIO {
         // bookkeeping of the level, done once per pair before the column kernel that follows:
         // exponent carried so far (this level's own is added by the consumer / the final
         // finalize) and a clean slot for this level's maximum
-        if (k1 == 0 && FA_TID == 0) {
-            G.L.wexp_out[P] = level_in_wexp(G.L, 2 * P) + level_in_wexp(G.L, 2 * P + 1);
-            G.L.max2_out[P] = 0ull;
-        }
+        const int wsum = level_in_wexp(G.L, 2 * P) + level_in_wexp(G.L, 2 * P + 1);   // wave-uniform
+        if (k1 == 0 && FA_TID == 0) G.L.wexp_out[P] = wsum;
+        if (k1 == 0 && FA_TID < kMax2Slots) G.L.max2_out[(size_t)P * kMax2Slots + FA_TID] = 0u;
     }
     // w_N^{k1 n2} for element n2 = v + (N2/R)*i of this lane (same for every polynomial) =
     // per-lane look-up w^{k1 v} times the workgroup-uniform factor w^{k1 (N2/R) i}; formed per
@@ -1548,12 +1563,12 @@ template <int N2, int R, bool DIRECT> FA_DEV void body_mid_sym(const BigLevel &G
     }
     FA_STAMP(G.stamps, 1);
     // ---- bookkeeping of the level (once per pair) and the factors every polynomial shares ------------
-    if (k1 == 0 && v == 0) {
-        L.wexp_out[P] = level_in_wexp(L, mA) + level_in_wexp(L, mB);
-        L.max2_out[P] = 0ull;
-    }
+    const int pendA = level_in_pending_exp(L, mA), pendB = level_in_pending_exp(L, mB);   // workgroup-uniform
+    if (k1 == 0 && v == 0) L.wexp_out[P] = L.wexp_in[mA] + pendA + L.wexp_in[mB] + pendB;
+    if (k1 == 0 && v < kMax2Slots) L.max2_out[(size_t)P * kMax2Slots + v] = 0u;
     const bool rescale = DIRECT || G.y_unscaled;
-    const double scA = rescale ? level_in_scale(L, mA) : 1.0, scB = rescale ? level_in_scale(L, mB) : 1.0;
+    const double scA = !rescale ? 1.0 : (L.in_pending ? pow2i(-pendA) : L.scale_in[mA]);
+    const double scB = !rescale ? 1.0 : (L.in_pending ? pow2i(-pendB) : L.scale_in[mB]);
     // w_N^{k1 n2}, n2 = v + (N2/R) i: per-lane w^{k1 v} times workgroup-uniform w^{k1 (N2/R) i}
     const cplx wbase = big_twiddle(G.btw, (unsigned)k1 * (unsigned)v);
     cplx wu[R];
@@ -1623,6 +1638,28 @@ template <int N2, int R, bool DIRECT> FA_DEV void body_mid_sym(const BigLevel &G
     FA_STAMP(G.stamps, 7);
 }
 
+// constant term ("tail") of entry e of the product of pair P of a split level, from the factors' tails
+// (and, symmetric form, the left factor's leading coefficients); sA, sB: pending scales of the factors
+FA_DEV cplx split_tail_product(const TreeLevel &L, int P, int e, double sA, double sB)
+{
+    TailSet t;
+    if (L.ne == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+            t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+        }
+        return tail_product_general(t, e);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
+        t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
+        t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
+    }
+    return tail_product_sym(t, e, L.kappa);
+}
+
 // column step of the inverse transform of every output polynomial
 //   grid.x = N2/BC tiles, grid.y = 4*n_out polynomials
 template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLevel &G)
@@ -1640,6 +1677,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
     const long long N = (long long)N1 * N2;
     const int d2 = 2 * L.d;
     const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);   // wave-uniform
     cplx x[R];
 #pragma unroll
     for (int i = 0; i < R; i++) {
@@ -1658,25 +1696,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
         cplx val = x[i] * inv;
         if (idx == 0) {
             // tails of the two factors -> constant term of the product, un-alias coefficient 0
-            const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
-            TailSet t;
-            cplx tp;
-            if (L.ne == 4) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-                }
-                tp = tail_product_general(t, e);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-                    t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
-                }
-                tp = tail_product_sym(t, e, L.kappa);
-            }
+            const cplx tp = split_tail_product(L, P, e, sA, sB);
             if (N == d2) val = val - tp;
             L.tail_out[(size_t)e * n_out + P] = tp;
             m2 = fmax(m2, cnorm2(tp));
@@ -1686,7 +1706,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_inv(const BigLeve
             m2 = fmax(m2, cnorm2(val));
         }
     }
-    fa_wave_atomic_max_f64bits(&L.max2_out[P], m2);   // P is uniform in the workgroup
+    fa_wave_atomic_max_hi32(&L.max2_out[(size_t)P * kMax2Slots + max2_slot()], m2);   // P is uniform in the workgroup
 }
 
 // Bridge between two consecutive split levels: inverse column step of level l (N = N1*N2)
@@ -1712,6 +1732,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
     const long long N = (long long)N1 * N2;
     const int d2 = 2 * L.d;
     const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);   // wave-uniform
     cplx x[2 * R];
 #pragma unroll
     for (int i = 0; i < R; i++) {
@@ -1730,25 +1751,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
     const double inv = 1.0 / (double)N1;
     double m2 = 0.0;
     // constant term of the product (needed by the lanes holding index 0 and index 2d)
-    auto tail_prod = [&]() -> cplx {
-        const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
-        TailSet t;
-        if (L.ne == 4) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-                t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-            }
-            return tail_product_general(t, e);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-            t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-            t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
-        }
-        return tail_product_sym(t, e, L.kappa);
-    };
+    auto tail_prod = [&]() -> cplx { return split_tail_product(L, P, e, sA, sB); };
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int n1 = v + (N1 / R) * i;
@@ -1772,7 +1775,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
         x[i] = val;
         x[R + i] = up;
     }
-    fa_wave_atomic_max_f64bits(&L.max2_out[P], m2);   // P is uniform in the workgroup
+    fa_wave_atomic_max_hi32(&L.max2_out[(size_t)P * kMax2Slots + max2_slot()], m2);   // P is uniform in the workgroup
     // forward column step of the next level: length 2*N1, 2R points per lane
     fft_wg<2 * N1, 2 * R, BC, -1, DB>(x, lds, v, c, G.tw1x2, parity);
     cplx *dst = G.Y + (size_t)poly * (2 * N1) * N2;
@@ -1804,6 +1807,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
     const int N2 = G.N2;
     const int d2 = 2 * L.d;
     const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);   // wave-uniform
     cplx x[R];
 #pragma unroll
     for (int i = 0; i < R; i++) x[i] = src[yz_index(N1, N2, v + (N1 / R) * i, n2)];
@@ -1813,24 +1817,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
     double m2 = 0.0;
     cplx tp = cmake(0.0, 0.0);
     if (n2 == 0 && v == 0) {   // the lane that holds index 0
-        const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
-        TailSet t;
-        if (L.ne == 4) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-                t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-            }
-            tp = tail_product_general(t, e);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-                t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-                t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
-            }
-            tp = tail_product_sym(t, e, L.kappa);
-        }
+        tp = split_tail_product(L, P, e, sA, sB);
         L.tail_out[(size_t)e * n_out + P] = tp;
         m2 = cnorm2(tp);
     }
@@ -1845,7 +1832,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
         m2 = fmax(m2, cnorm2(val));
         x[i] = val * G.tw1x2[n1];   // * w_{2N1}^{n1}
     }
-    fa_wave_atomic_max_f64bits(&L.max2_out[P], m2);   // P is uniform in the workgroup
+    fa_wave_atomic_max_hi32(&L.max2_out[(size_t)P * kMax2Slots + max2_slot()], m2);   // P is uniform in the workgroup
     fft_wg<N1, R, BC, -1, DB, true>(x, lds, v, c, G.tw1, parity);
     cplx *dst = G.Y + (size_t)poly * N1 * N2;   // odd rows only: [poly][j][n2]
     // column 0: the tail at index N contributes t * w_{2N1}^{N1 (2j+1)} = -t to every odd row
@@ -1853,27 +1840,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
     cplx tpc = cmake(0.0, 0.0);
     if (col0) {
         // every lane of column 0 needs t: recompute it (cheap, uniform within the few lanes)
-        if (v == 0) tpc = tp;
-        else {
-            const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);
-            TailSet t;
-            if (L.ne == 4) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-                }
-                tpc = tail_product_general(t, e);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    t.tA[q] = L.tail_in[(size_t)q * L.n_in + 2 * P] * sA;
-                    t.tB[q] = L.tail_in[(size_t)q * L.n_in + 2 * P + 1] * sB;
-                    t.leadA[q] = L.body_in[(size_t)q * L.plane + (size_t)(2 * P) * L.d] * sA;
-                }
-                tpc = tail_product_sym(t, e, L.kappa);
-            }
-        }
+        tpc = (v == 0) ? tp : split_tail_product(L, P, e, sA, sB);
     }
 #pragma unroll
     for (int i = 0; i < R; i++) {
@@ -1888,7 +1855,12 @@ FA_DEV void body_finalize_scales(const TreeLevel &L)
 {
     const long long P = (long long)FA_BID * FA_BDIM + FA_TID;
     if (P >= L.n_in / 2) return;
-    const int a = exponent_of_max2(L.max2_out[P]);
+    unsigned hi = 0u;
+    for (int sl = 0; sl < kMax2Slots; sl++) {
+        const unsigned x = L.max2_out[(size_t)P * kMax2Slots + sl];
+        hi = x > hi ? x : hi;
+    }
+    const int a = exponent_of_max2(hi);
     L.scale_out[P] = pow2i(-a);
     L.wexp_out[P] = L.wexp_out[P] + a;
 }

@@ -121,7 +121,7 @@ public:
     cplx *body[2] = {nullptr, nullptr};
     cplx *tail[2] = {nullptr, nullptr};
     double *scale[2] = {nullptr, nullptr};
-    unsigned long long *max2[2] = {nullptr, nullptr};  // ping-pong across split levels
+    unsigned *max2[2] = {nullptr, nullptr};  // ping-pong across split levels, kMax2Slots per matrix
     int *wexp[2] = {nullptr, nullptr};  // per matrix, ping-pong with body/tail/scale
     int *status = nullptr;
     // monomial program of the order 5..8 schemes (nft_schemes.h), device copies
@@ -218,7 +218,10 @@ public:
             ok = ok && alloc(body[i], 4 * plane) && alloc(tail[i], 4 * n0) && alloc(scale[i], n0)
                  && alloc(wexp[i], n0);
         }
-        ok = ok && alloc(max2[0], n0) && alloc(max2[1], n0) && alloc(status, 4);
+        {   // split levels hold at most n0*deg0/2048 matrices, kMax2Slots slots each
+            const size_t nm = n0 * (size_t)deg0 / 32 + 4 * (size_t)kMax2Slots;
+            ok = ok && alloc(max2[0], nm) && alloc(max2[1], nm) && alloc(status, 4);
+        }
         {   // scratch of the split transforms: 4*n_in polynomials of N forward, 4*n_out inverse,
             // maximised over the levels that use them (N can exceed 2d when d is not 2^k)
             size_t needY = 0, needZ = 0, n = n0, d = (size_t)deg0;

@@ -71,10 +71,24 @@ static int plan_init(orc_plan *pl, size_t len, int sign)
      * angle, kiss_fft.c:357-363; the rounding of the angle is a bias common to every transform of
      * the tree and accumulates linearly in the number of products -- the checker avoids it.) */
     const long double tau = 6.283185307179586476925286766559005768L;
-    for (size_t k = 0; k < len; k++) {
+    /* first half by cosl/sinl, second half by the symmetry tw[len-k] = conj(tw[k]) */
+    for (size_t k = 0; k <= len / 2; k++) {
         const long double ang = (long double)sign * tau * (long double)k / (long double)len;
         pl->tw[k] = (double)cosl(ang) + I * (double)sinl(ang);
     }
+    for (size_t k = len / 2 + 1; k < len; k++) pl->tw[k] = conj(pl->tw[len - k]);
+    return ORC_SUCCESS;
+}
+
+/* plan of the opposite direction of an existing one: its table is the complex conjugate */
+static int plan_init_conj(orc_plan *pl, const orc_plan *other)
+{
+    memcpy(pl, other, sizeof(*pl));
+    pl->sign = -other->sign;
+    pl->tw = malloc(other->len * sizeof(orc_cplx));
+    pl->work = malloc(other->len * sizeof(orc_cplx));
+    if (!pl->tw || !pl->work) return ORC_EC_NOMEM;
+    for (size_t k = 0; k < other->len; k++) pl->tw[k] = conj(other->tw[k]);
     return ORC_SUCCESS;
 }
 
@@ -92,33 +106,53 @@ static void stockham_pass(const orc_plan *pl, size_t n_cur, size_t s, int r,
 {
     const size_t len = pl->len;
     const size_t m = n_cur / (size_t)r;
-    const size_t tstep = len / n_cur; /* w_{n_cur}^a = tw[a*tstep] */
+    const size_t tstep = len / n_cur; /* w_{n_cur}^a = tw[a*tstep]; a = k*p < r*m = n_cur, so a*tstep < len */
     const size_t rstep = len / (size_t)r;
+    const size_t sm = s * m;
     const double sg = (double)pl->sign;
-    for (size_t p = 0; p < m; p++) {
-        for (size_t q = 0; q < s; q++) {
-            const orc_cplx *xin = x + q + s * p;
-            orc_cplx *yout = y + q + s * (size_t)r * p;
-            if (r == 2) {
-                orc_cplx a = xin[0], b = xin[s * m];
-                yout[0] = a + b;
-                yout[s] = (a - b) * pl->tw[p * tstep];
-            } else if (r == 4) {
-                orc_cplx a = xin[0], b = xin[s * m], c = xin[2 * s * m], d = xin[3 * s * m];
-                orc_cplx apc = a + c, amc = a - c, bpd = b + d;
-                orc_cplx jbmd = (I * sg) * (b - d); /* w_4^1 = sign*i */
-                yout[0] = apc + bpd;
-                yout[s] = (amc + jbmd) * pl->tw[p * tstep];
-                yout[2 * s] = (apc - bpd) * pl->tw[(2 * p * tstep) % len];
-                yout[3 * s] = (amc - jbmd) * pl->tw[(3 * p * tstep) % len];
-            } else {
+    const orc_cplx *tw = pl->tw;
+    if (r == 2) {
+        for (size_t p = 0; p < m; p++) {
+            const orc_cplx w1 = tw[p * tstep];
+            const orc_cplx *xin = x + s * p;
+            orc_cplx *yout = y + s * 2 * p;
+            for (size_t q = 0; q < s; q++) {
+                const orc_cplx a = xin[q], b = xin[q + sm];
+                yout[q] = a + b;
+                yout[q + s] = (a - b) * w1;
+            }
+        }
+    } else if (r == 4) {
+        for (size_t p = 0; p < m; p++) {
+            const orc_cplx w1 = tw[p * tstep], w2 = tw[2 * p * tstep], w3 = tw[3 * p * tstep];
+            const orc_cplx *xin = x + s * p;
+            orc_cplx *yout = y + s * 4 * p;
+            for (size_t q = 0; q < s; q++) {
+                const orc_cplx a = xin[q], b = xin[q + sm], c = xin[q + 2 * sm], d = xin[q + 3 * sm];
+                const orc_cplx apc = a + c, amc = a - c, bpd = b + d, bmd = b - d;
+                /* w_4^1 * (b - d) = sign*i*(b - d) */
+                const orc_cplx jbmd = -sg * cimag(bmd) + I * (sg * creal(bmd));
+                yout[q] = apc + bpd;
+                yout[q + s] = (amc + jbmd) * w1;
+                yout[q + 2 * s] = (apc - bpd) * w2;
+                yout[q + 3 * s] = (amc - jbmd) * w3;
+            }
+        }
+    } else {
+        orc_cplx wr[25], wp[5];
+        for (int k = 0; k < r; k++)
+            for (int j = 0; j < r; j++) wr[k * r + j] = tw[((size_t)(j * k) % (size_t)r) * rstep];
+        for (size_t p = 0; p < m; p++) {
+            for (int k = 0; k < r; k++) wp[k] = tw[(size_t)k * p * tstep];
+            const orc_cplx *xin = x + s * p;
+            orc_cplx *yout = y + s * (size_t)r * p;
+            for (size_t q = 0; q < s; q++) {
                 orc_cplx v[5];
-                for (int j = 0; j < r; j++) v[j] = xin[(size_t)j * s * m];
+                for (int j = 0; j < r; j++) v[j] = xin[q + (size_t)j * sm];
                 for (int k = 0; k < r; k++) {
                     orc_cplx acc = v[0];
-                    for (int j = 1; j < r; j++)
-                        acc += v[j] * pl->tw[(((size_t)(j * k) % (size_t)r) * rstep) % len];
-                    yout[(size_t)k * s] = acc * pl->tw[((size_t)k * p * tstep) % len];
+                    for (int j = 1; j < r; j++) acc += v[j] * wr[k * r + j];
+                    yout[q + (size_t)k * s] = acc * wp[k];
                 }
             }
         }
@@ -365,8 +399,9 @@ int orc_poly_fmult2x2(size_t *d, size_t n, orc_cplx *p, orc_cplx *result, int32_
     while (n >= 2) { /* :460-519 */
         const size_t len = orc_next_fast_size(2 * (deg + 1) - 1);
         orc_plan fwd, inv;
+        memset(&inv, 0, sizeof inv);
         rc = plan_init(&fwd, len, -1);
-        if (rc == ORC_SUCCESS) rc = plan_init(&inv, len, +1);
+        if (rc == ORC_SUCCESS) rc = plan_init_conj(&inv, &fwd);
         if (rc != ORC_SUCCESS) { plan_free(&fwd); plan_free(&inv); break; }
         r_stride = (n / 2) * (2 * deg + 1);
         for (size_t i = 0; i < n; i += 2) {
@@ -418,7 +453,7 @@ int orc_poly_chirpz(size_t deg, const orc_cplx *p, orc_cplx A, orc_cplx W, size_
     memset(&fwd, 0, sizeof fwd);
     memset(&inv, 0, sizeof inv);
     if (rc == ORC_SUCCESS) rc = plan_init(&fwd, L, -1);
-    if (rc == ORC_SUCCESS) rc = plan_init(&inv, L, +1);
+    if (rc == ORC_SUCCESS) rc = plan_init_conj(&inv, &fwd);
     if (rc == ORC_SUCCESS) {
         for (size_t n = 0; n < N; n++) { /* :68-71 */
             const double dn = (double)n;
