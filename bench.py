@@ -13,9 +13,10 @@ D = M = 2^20 complex128 samples, q = 3.2i*sech(t), T = [-25, 25], XI = [-7/5, 8/
 GPUs = 64 signals per GPU in one batched plan, XI = [-4, 4]); the default is the headline configs[1].
 
 With N ranks every rank transforms its own signal (weak scaling, no data-path collective: the signals
-are independent).  The job's ONE RCCL gather collects the result shards of the last step on rank 0
-inside the timed region (`--gather job`, default); `--gather step` gathers after every step
-(overlapped with the next step's compute), `--gather none` leaves the results sharded.
+are independent).  One RCCL gather per step collects the result shards on rank 0
+after EVERY step inside the timed region (`--gather step`, default: K steps = K gathered result sets,
+each gather overlapped with the next step's compute); `--gather job` gathers only the last step's shards,
+`--gather none` leaves the results sharded.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -117,10 +118,10 @@ def main():
                     help="cfg2: one signal D=M=2^20 per GPU (headline); cfg3: BASELINE.json configs[2], "
                          "64 of the 512 signals D=M=2^16 per GPU; cfg5: configs[4], fnft_kdvv D=M=2^18 2SPLIT8B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", choices=("job", "step", "none"), default="job",
-                    help="N>1: 'job' = ONE RCCL gather of the result shards per job (after the last of the K "
-                         "steps, inside the timed region); 'step' = a gather after every step, overlapped "
-                         "with the next step; 'none' = results stay sharded")
+    ap.add_argument("--gather", choices=("job", "step", "none"), default="step",
+                    help="N>1: 'step' (default) = the result shards of EVERY step are gathered on rank 0 inside the "
+                         "timed region (RCCL, overlapped with the next step's compute); 'job' = only the last "
+                         "step's shards are gathered; 'none' = results stay sharded")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 control-flow rehearsal on a box with fewer GPUs than ranks: gloo backend, "
@@ -267,13 +268,16 @@ def main():
         # KdV has no NSE symmetry and r = -1: the general 4-entry tree, same byte model
         bt = B * bytes_tree(D, deg0)
         achieved = bt / (t_tree * 1e-3) / 1e9
+        # HBM bytes of the tree launches of one step from the PMC passes of this build (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs of this command, FETCH doubled as the microarch guide
+        # prescribes; profiles/traffic_from_pmc.py writes the file).  Counters cannot be read from inside
+        # the process, so the number is the committed one for this workload, or null.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_tree_traffic.json")
-        if os.path.exists(tpath) and args.log2D == 20 and args.disc == "2SPLIT2_MODAL" and not cfg3:
-            # measured HBM bytes of the same launches (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate passes, FETCH doubled as the microarch guide prescribes); see profiles/
+        tpath = os.path.join(ROOT, "profiles", "tree_traffic.json")
+        wkey = "%s/D=2^%d/%s/B=%d" % (args.workload, args.log2D, args.disc, B)
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f)["tree_hbm_bytes_per_transform"]
+                traffic = (json.load(f).get(wkey) or {}).get("tree_hbm_bytes_per_step")
         stages = launch_breakdown(plan, lambda: transform(outs[0].data_ptr()), reps, B, D, deg0)
         roof = {"bound": "hbm", "kernel": "poly_fmult2x2 tree (coefficients + all level launches of one transform)",
                 "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -281,6 +285,31 @@ def main():
                 "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
                 "chirpz_epilogue_ms": round(float(chirp_ms), 4), "stages": stages,
                 "launches_us": getattr(launch_breakdown, "last_launches", None)}
+        if world == 1 and not cfg5:
+            # (i) cold spectral grid: `value` reuses the spectrum of the chirp filter the plan keeps between
+            # calls on the same (T, XI) grids (plan data, like a twiddle table); a call on a NEW grid forms it
+            # again as fnft__poly_chirpz.c:76-84 does on every call.  Every step here gets its own XI.
+            torch.cuda.synchronize()
+            tcg0 = time.perf_counter()
+            for i in range(args.steps):
+                xi_i = [XI[0], XI[1] * (1.0 + 1e-9 * (i + 1))]
+                rc = plan.contspec_device(dq.data_ptr(), outs[0].data_ptr(), T, xi_i, kappa=1, contspec_type="BOTH",
+                                          normalization_flag=1, stream=stream)
+                if rc != 0:
+                    raise RuntimeError("cold-grid step rc=%d: %s" % (rc, capi.last_error()))
+            torch.cuda.synchronize()
+            roof["cold_grid_ms_per_step"] = round((time.perf_counter() - tcg0) * 1e3 / args.steps, 4)
+            # (ii) the drop-in itself: fnft_nsev() with HOST pointers (PCIe both ways, plan from the cache)
+            hq = q_host[0] if cfg3 else q_host
+            th = []
+            for i in range(4):
+                th0 = time.perf_counter()
+                rch, _ = capi.fnft_nsev(hq, T, M, XI, kappa=1, discretization=args.disc, contspec_type="BOTH")
+                th.append((time.perf_counter() - th0) * 1e3)
+                if rch != 0:
+                    raise RuntimeError("fnft_nsev (host pointers) rc=%d: %s" % (rch, capi.last_error()))
+            roof["host_call_ms"] = round(float(np.median(th[1:])), 4)
+            roof["host_call_Msamples_per_s"] = round(D / (roof["host_call_ms"] * 1e-3) / 1e6, 1)
         if not args.no_cpu_baseline and world == 1:   # the CPU checker is timed at N = 1 only
             from oracle import load_oracle
             orc = load_oracle()
@@ -303,7 +332,13 @@ def main():
                     for j in range(nout):
                         worst[j] = max(worst[j], float(S.rel_err(res[k, j], ref[j * M:(j + 1) * M])))
             err = dict(zip(("rho", "a", "b")[:nout], worst)) if res is not None else None
+            # oracle time / reference time for the same call, measured in the build container where the
+            # reference could be run (the reference cannot travel to this box)
+            ref_ratio = {"D=2^12 2SPLIT2_MODAL": 1.19, "D=2^12 2SPLIT4B": 1.31, "D=2^16 2SPLIT2_MODAL": 1.20,
+                         "D=2^16 2SPLIT4B": 1.04, "D=2^18 2SPLIT2_MODAL": 0.94, "D=2^18 2SPLIT4B": 0.94,
+                         "D=2^20 2SPLIT2_MODAL": 0.90}.get("D=2^%d %s" % (int(math.log2(Dc)), args.disc))
             cpu = {"value": round(nc * Dc / tc / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                   "reference_ratio": ref_ratio,
                    "sample": "%d signal(s), D=M=2^%d, %s, oracle/fnft_oracle.c single thread, %.1f s"
                              % (nc, int(math.log2(Dc)), args.disc, tc),
                    "host_cpus": os.cpu_count(), "gpu_vs_cpu_rel_l1": err}

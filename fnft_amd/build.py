@@ -1,11 +1,15 @@
 """Build libfnft_amd.so (hipcc, gfx950) in-tree: fnft_amd/lib/libfnft_amd.so.
 
-Usage: python -m fnft_amd.build [--force]
+Usage: python -m fnft_amd.build [--force] [-j N]
 The library is the product; it has no CPU fallback.  hipcc cross-compiles without a GPU.
+The HIP side is several translation units (csrc/hip_backend.hip + csrc/hip_kernels_*.hip, see
+csrc/hip_be.h) compiled in parallel; only units whose object is older than the sources are rebuilt.
 """
+import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -13,9 +17,15 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfnft_amd.so")
 ARCH = "gfx950"
 
-SOURCES = ["hip_backend.hip", "fnft_nsev_host.c", "fnft_kdvv_host.c"]
-HEADERS = ["dev_compat.h", "fft_dev.h", "nft_kernels.h", "nft_dispatch.h", "nft_plan.h", "nft_api.h", "nft_schemes.h", "nft_discspec.h",
-           os.path.join("..", "..", "include", "fnft_amd.h")]
+C_SOURCES = ["fnft_nsev_host.c", "fnft_kdvv_host.c"]
+
+
+def hip_sources():
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "fnft_amd.h")]
 
 
 def _newest(paths):
@@ -25,41 +35,54 @@ def _newest(paths):
 def needs_build():
     if not os.path.exists(LIB):
         return True
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in hip_sources() + C_SOURCES] + headers()
     return _newest(deps) > os.path.getmtime(LIB)
 
 
-def build(force=False, verbose=False, defs=None, out=None):
+def build(force=False, verbose=False, defs=None, out=None, jobs=None):
     """defs / out: diagnostic variants (tests/gpu_debug/build_variant.py) -- extra -D flags and another
     output path; the product library is always build() with neither."""
     if out is None and not force and not needs_build():
         return LIB
     lib = out or LIB
-    libdir = os.path.dirname(lib) if out else LIBDIR
-    os.makedirs(libdir, exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "hipcc")
-    objs = []
-    extra = list(defs) if defs else os.environ.get("FNFT_AMD_DEFS", "").split()
     tag = os.path.splitext(os.path.basename(lib))[0]
-    cmds = [
-        [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + extra + ["-c",
-         os.path.join(CSRC, "hip_backend.hip"), "-o", os.path.join(libdir, tag + "_hip_backend.o" if out else "hip_backend.o")],
-        [hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c",
-         os.path.join(CSRC, "fnft_nsev_host.c"), "-o", os.path.join(libdir, tag + "_nsev_host.o" if out else "fnft_nsev_host.o")],
-        [hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c",
-         os.path.join(CSRC, "fnft_kdvv_host.c"), "-o", os.path.join(libdir, tag + "_kdvv_host.o" if out else "fnft_kdvv_host.o")],
-    ]
-    for c in cmds:
+    objdir = os.path.join(os.path.dirname(lib), "obj_" + tag) if out else LIBDIR
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    extra = list(defs) if defs else os.environ.get("FNFT_AMD_DEFS", "").split()
+    hdr_time = _newest(headers())
+    stamp = os.path.join(objdir, "flags.txt")
+    flags_changed = (not os.path.exists(stamp)) or open(stamp).read() != " ".join(extra)
+    cmds, objs = [], []
+    for src in hip_sources():
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        sp = os.path.join(CSRC, src)
+        if force or flags_changed or not os.path.exists(o) or os.path.getmtime(o) < max(hdr_time, os.path.getmtime(sp)):
+            cmds.append([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", sp, "-o", o])
+    for src in C_SOURCES:
+        o = os.path.join(objdir, src.replace(".c", ".o"))
+        objs.append(o)
+        sp = os.path.join(CSRC, src)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(hdr_time, os.path.getmtime(sp)):
+            cmds.append([hipcc, "-O2", "-std=c11", "-fPIC", "-x", "c", "-c", sp, "-o", o])
+
+    def run(c):
         if verbose:
             print(" ".join(c), flush=True)
         subprocess.check_call(c)
-        objs.append(c[-1])
-    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
-    if verbose:
-        print(" ".join(link), flush=True)
-    subprocess.check_call(link)
+
+    n = jobs or int(os.environ.get("FNFT_AMD_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))
+    with ThreadPoolExecutor(max_workers=max(1, n)) as ex:
+        list(ex.map(run, cmds))
+    with open(stamp, "w") as f:
+        f.write(" ".join(extra))
+    # -z defs: a kernel the host logic launches but no hip_kernels_*.hip instantiates fails HERE, not at load time
+    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib] + objs
+    run(link)
     return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    j = int(sys.argv[sys.argv.index("-j") + 1]) if "-j" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose=True, jobs=j))

@@ -334,34 +334,52 @@ template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2P
     }
 
     // entered with X's pass-p inputs in registers and Y's pass-p inputs READ ISSUED (or, for the
-    // first pass, in registers)
+    // first pass, in registers).  hook(k) is called once per barrier interval, k = 0, 1, 2, ... (two per
+    // pass): the caller's chance to put independent work -- global loads of the NEXT operands -- into
+    // the instruction stream of this transform.
+    template <class Hook>
     static FA_DEV void run(cplx (&x)[R], cplx (&y)[R], cplx *bufX, cplx *bufY, int v, int c,
-                           const cplx *__restrict__ tw)
+                           const cplx *__restrict__ tw, Hook &hook, int k0)
     {
         bfly(x, v, tw);
         if constexpr (last) {
+            hook(k0);
             bfly(y, v, tw);
+            hook(k0 + 1);
         } else {
             write(x, bufX, v, c);
+            hook(k0);
             FA_SYNC_LDS();
             read(x, bufX, v, c);
             bfly(y, v, tw);
             write(y, bufY, v, c);
+            hook(k0 + 1);
             FA_SYNC_LDS();
             read(y, bufY, v, c);
-            Fft2Pass<N, R, B, SIGN, NCUR / r, S * r, TWC>::run(x, y, bufX, bufY, v, c, tw);
+            Fft2Pass<N, R, B, SIGN, NCUR / r, S * r, TWC>::run(x, y, bufX, bufY, v, c, tw, hook, k0 + 2);
         }
     }
 };
 template <int N, int R, int B, int SIGN, int S, bool TWC> struct Fft2Pass<N, R, B, SIGN, 1, S, TWC> {
-    static FA_DEV void run(cplx (&)[R], cplx (&)[R], cplx *, cplx *, int, int, const cplx *__restrict__) {}
+    template <class Hook>
+    static FA_DEV void run(cplx (&)[R], cplx (&)[R], cplx *, cplx *, int, int, const cplx *__restrict__, Hook &, int) {}
 };
 
+struct FftNoHook {
+    FA_DEV void operator()(int) const {}
+};
+
+template <int N, int R, int B, int SIGN, bool TWC = false, class Hook>
+FA_DEV void fft_wg2(cplx (&x)[R], cplx (&y)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw, Hook &hook)
+{
+    static_assert(N >= R, "fft_wg2: N must be at least R");
+    Fft2Pass<N, R, B, SIGN, N, 1, TWC>::run(x, y, lds, lds + (size_t)N * B, v, c, tw, hook, 0);
+}
 template <int N, int R, int B, int SIGN, bool TWC = false>
 FA_DEV void fft_wg2(cplx (&x)[R], cplx (&y)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw)
 {
-    static_assert(N >= R, "fft_wg2: N must be at least R");
-    Fft2Pass<N, R, B, SIGN, N, 1, TWC>::run(x, y, lds, lds + (size_t)N * B, v, c, tw);
+    FftNoHook h;
+    fft_wg2<N, R, B, SIGN, TWC>(x, y, lds, v, c, tw, h);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -321,11 +321,14 @@ template <int N0, int STAGES> struct MultiCfg {
     static constexpr int BF = THREADS * R / NF;
     static constexpr int P0 = BF << (STAGES - 1);
 #ifndef FA_MULTI_DB
-#define FA_MULTI_DB 1
+#define FA_MULTI_DB 2
 #endif
-    // double-buffered transform exchange (one barrier per pass): 0 never, 1 for the 512-lane
-    // configuration only, 2 always
-    static constexpr bool DB = (FA_MULTI_DB == 2) || (FA_MULTI_DB == 1 && THREADS == 512);
+#ifndef FA_LEAFMULTI_DB
+#define FA_LEAFMULTI_DB 0
+#endif
+    // buffering mode (nft_kernels.h, MultiStage): 0 single buffer, 1 double buffer, 2 pair-interleaved transforms
+    static constexpr int DB = FA_MULTI_DB;
+    static constexpr int DB_LEAF = FA_LEAFMULTI_DB;
 };
 template <int N0, int STAGES> struct KMulti {
     using Params = TreeLevel;
@@ -335,7 +338,7 @@ template <int N0, int STAGES> struct KMulti {
     static constexpr size_t lds_bytes()
     {
         constexpr size_t tw = (N0 * ((1 << STAGES) - 1) <= 1024) ? (size_t)N0 * ((1 << STAGES) - 1) : 0;
-        return ((size_t)((C::DB || FA_MULTI_PAIR2) ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw) * sizeof(cplx)
+        return ((size_t)((C::DB != 0) ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw) * sizeof(cplx)
                + (size_t)((C::BF + 1) & ~1) * sizeof(unsigned long long);
     }
     static FA_DEV void body(const Params &p) { body_multi_fft<N0, STAGES, C::R, C::BF, C::DB>(p); }
@@ -350,10 +353,10 @@ template <int DEG, int STAGES> struct KLeafMulti {
     static constexpr size_t lds_bytes()
     {
         constexpr size_t tw = (size_t)(2 * DEG * SPT) * ((1 << STAGES) - 1);
-        return ((size_t)((C::DB || FA_MULTI_PAIR2) ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw + (size_t)2 * C::THREADS) * sizeof(cplx)
+        return ((size_t)((C::DB_LEAF != 0) ? 2 : 1) * C::THREADS * C::R + (size_t)4 * C::P0 + tw + (size_t)2 * C::THREADS) * sizeof(cplx)
                + (size_t)((C::BF + 1) & ~1) * sizeof(unsigned long long) + (size_t)C::THREADS * sizeof(int);
     }
-    static FA_DEV void body(const Params &p) { body_leaf_multi<DEG, SPT, STAGES, C::R, C::BF, C::DB>(p); }
+    static FA_DEV void body(const Params &p) { body_leaf_multi<DEG, SPT, STAGES, C::R, C::BF, C::DB_LEAF>(p); }
 };
 template <class BE> bool dispatch_leaf_multi(BE &be, const LeafMultiParams &Q, int stages)
 {
@@ -388,7 +391,7 @@ template <class BE> void run_mid(BE &be, const BigLevel &G)
 {
     const int g = (G.L.n_in / 2) * G.N1;
     if (G.L.ne == 4) be.template run<KMid<4>>(g, 1, G);
-    else if (!FA_MID_SYM) be.template run<KMid<2>>(g, 1, G);
+    else if constexpr (!FA_MID_SYM) be.template run<KMid<2>>(g, 1, G);
     else if (G.y_direct) be.template run<KMidSym<true>>(g, 1, G);
     else be.template run<KMidSym<false>>(g, 1, G);
 }

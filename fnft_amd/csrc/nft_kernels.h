@@ -883,27 +883,25 @@ template <int N, int R, int B, bool DB, int NE> FA_DEV void body_pair_fft(const 
 // NF = N0 * 2^(STAGES-1).
 // LDS: T*R transform/staging elements, then per stage the tails (2 per product), then BF maxima.
 // ---------------------------------------------------------------------------------------------
-// FA_MULTI_PAIR2: the transforms of a stage run in pairs (fft_wg2: two single LDS buffers bufX = lds,
+// DB (buffering mode of the multi-level kernels): 0 one LDS transform buffer (two barriers per exchange),
+// 1 two buffers used alternately (one barrier), 2 the transforms of a stage run in pairs (fft_wg2: two single LDS buffers bufX = lds,
 // bufY = lds + T*R).  The products then cross to the next stage through bufX (entry 11) and bufY
 // (entry 21): bufX is free once fft_wg2 returns (its last reads precede the final barrier), bufY after
 // the barrier that follows the entry-11 hand-over.
-#ifndef FA_MULTI_PAIR2
-#define FA_MULTI_PAIR2 1
-#endif
-template <int N, int R, int PAIRS, bool DB, bool TWC> struct MultiStage {
+template <int N, int R, int PAIRS, int DB, bool TWC> struct MultiStage {
     // symmetric pair product of the `PAIRS` pairs held by the workgroup; on entry a11.. hold the
     // factors (natural order, zero padded), on exit c11 / c21 the cyclic products times N
     static FA_DEV void product(cplx (&a11)[R], cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], cplx *lds, int v,
                                int c, const cplx *tw, int kappa, int &parity)
     {
-        if constexpr (FA_MULTI_PAIR2) {
+        if constexpr (DB == 2) {
             fft_wg2<N, R, PAIRS, -1, TWC>(a11, a21, lds, v, c, tw);
             fft_wg2<N, R, PAIRS, -1, TWC>(b11, b21, lds, v, c, tw);
         } else {
-            fft_wg<N, R, PAIRS, -1, DB, TWC>(a11, lds, v, c, tw, parity);
-            fft_wg<N, R, PAIRS, -1, DB, TWC>(a21, lds, v, c, tw, parity);
-            fft_wg<N, R, PAIRS, -1, DB, TWC>(b11, lds, v, c, tw, parity);
-            fft_wg<N, R, PAIRS, -1, DB, TWC>(b21, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, -1, DB == 1, TWC>(a11, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, -1, DB == 1, TWC>(a21, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, -1, DB == 1, TWC>(b11, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, -1, DB == 1, TWC>(b21, lds, v, c, tw, parity);
         }
         // g[m] = exp(-2 pi i d m/N) = (-1)^m for N = 2d; m = v + (N/R) i has the parity of v (N/R even)
         const double g = ((N / R) % 2 == 0) ? ((v & 1) ? -1.0 : 1.0) : 0.0;
@@ -917,11 +915,11 @@ template <int N, int R, int PAIRS, bool DB, bool TWC> struct MultiStage {
             b11[i] = c11;
             b21[i] = c21;
         }
-        if constexpr (FA_MULTI_PAIR2) {
+        if constexpr (DB == 2) {
             fft_wg2<N, R, PAIRS, +1, TWC>(b11, b21, lds, v, c, tw);
         } else {
-            fft_wg<N, R, PAIRS, +1, DB, TWC>(b11, lds, v, c, tw, parity);
-            fft_wg<N, R, PAIRS, +1, DB, TWC>(b21, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, +1, DB == 1, TWC>(b11, lds, v, c, tw, parity);
+            fft_wg<N, R, PAIRS, +1, DB == 1, TWC>(b21, lds, v, c, tw, parity);
         }
     }
 };
@@ -937,7 +935,7 @@ FA_DEV cplx multi_tail(int e, cplx tA0, cplx tA1, cplx tB0, cplx tB1, cplx lead0
     return tail_product_sym(t, e, kappa);
 }
 
-template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
+template <int N0, int STAGES, int R, int BF, int DB, int S> struct MultiRun {
     static constexpr int N = N0 << S;                      // transform length of this stage
     static constexpr int PAIRS = BF << (STAGES - 1 - S);   // pairs of this stage
     static constexpr int T = BF * (N0 << (STAGES - 1)) / R;
@@ -988,8 +986,8 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
             for (int e = 0; e < 2; e++) {
                 // single buffer: wait until the last exchange has been read; double buffer: the idle
                 // one is free by the hand-over rule of fft_wg
-                cplx *stg = FA_MULTI_PAIR2 ? lds + (size_t)e * kBufElems : (DB ? lds + (size_t)parity * kBufElems : lds);
-                if (!DB && !FA_MULTI_PAIR2) FA_SYNC_LDS();
+                cplx *stg = (DB == 2) ? lds + (size_t)e * kBufElems : ((DB == 1) ? lds + (size_t)parity * kBufElems : lds);
+                if (DB == 0) FA_SYNC_LDS();
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int idx = v + (N / R) * i;
@@ -1021,7 +1019,7 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
 #pragma unroll
                     for (int i = 0; i < R; i++) { a21[i] = na[i]; b21[i] = nb[i]; }
                 }
-                if (DB && !FA_MULTI_PAIR2) parity ^= 1;
+                if (DB == 1) parity ^= 1;
             }
             MultiRun<N0, STAGES, R, BF, DB, S + 1>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity, ltail,
                                                         lwexp);
@@ -1030,8 +1028,8 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
             const int n_out = n_stage >> 1;
             double m2 = 0.0;
             for (int e = 0; e < 2; e++) {
-                cplx *stg = FA_MULTI_PAIR2 ? lds + (size_t)e * kBufElems : (DB ? lds + (size_t)parity * kBufElems : lds);
-                if (!DB && !FA_MULTI_PAIR2) FA_SYNC_LDS();
+                cplx *stg = (DB == 2) ? lds + (size_t)e * kBufElems : ((DB == 1) ? lds + (size_t)parity * kBufElems : lds);
+                if (DB == 0) FA_SYNC_LDS();
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int idx = v + (N / R) * i;
@@ -1058,7 +1056,7 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
                     const int rot = (i3 + c3) & (N - 1);
                     out0[m] = stg[(size_t)c3 * N + rot];
                 }
-                if (DB && !FA_MULTI_PAIR2) parity ^= 1;
+                if (DB == 1) parity ^= 1;
             }
             if (act) fa_atomic_max_u64(&mx[c], dbits(m2));
             FA_SYNC_LDS();
@@ -1076,7 +1074,7 @@ template <int N0, int STAGES, int R, int BF, bool DB, int S> struct MultiRun {
         }
     }
 };
-template <int N0, int STAGES, int R, int BF, bool DB, int S>
+template <int N0, int STAGES, int R, int BF, int DB, int S>
 FA_DEV void multi_stage_run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned long long *mx, cplx (&a11)[R],
                             cplx (&a21)[R], cplx (&b11)[R], cplx (&b21)[R], long long mat0, const cplx *const *twp)
 {
@@ -1084,14 +1082,14 @@ FA_DEV void multi_stage_run(const TreeLevel &L, cplx *lds, cplx *tails, unsigned
     MultiRun<N0, STAGES, R, BF, DB, S>::run(L, lds, tails, mx, a11, a21, b11, b21, mat0, twp, parity);
 }
 
-template <int N0, int STAGES, int R, int BF, bool DB> FA_DEV void body_multi_fft(const TreeLevel &L)
+template <int N0, int STAGES, int R, int BF, int DB> FA_DEV void body_multi_fft(const TreeLevel &L)
 {
     constexpr int NF = N0 << (STAGES - 1);
     constexpr int T = BF * NF / R;
     constexpr int P0 = BF << (STAGES - 1);          // pairs of stage 0
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
-    cplx *tails = lds + (size_t)((DB || FA_MULTI_PAIR2) ? 2 : 1) * T * R;   // [stage][pair][2]
+    cplx *tails = lds + (size_t)((DB != 0) ? 2 : 1) * T * R;   // [stage][pair][2]
     unsigned long long *mx = (unsigned long long *)(tails + (size_t)2 * 2 * P0);
     const int tid = FA_TID;
     const long long blk = FA_BID;
@@ -1154,7 +1152,7 @@ struct LeafMultiParams {
     LeafParams lp;
     TreeLevel L;      // n_in = matrices the leaf produces, d = DEG*SPT; *_in are unused
 };
-template <int DEG, int SPT, int STAGES, int R, int BF, bool DB> FA_DEV void body_leaf_multi(const LeafMultiParams &Q)
+template <int DEG, int SPT, int STAGES, int R, int BF, int DB> FA_DEV void body_leaf_multi(const LeafMultiParams &Q)
 {
     constexpr int d = DEG * SPT;
     constexpr int N0 = 2 * d;
@@ -1165,7 +1163,7 @@ template <int DEG, int SPT, int STAGES, int R, int BF, bool DB> FA_DEV void body
     static_assert(T == 2 * P0, "lanes = matrices of the block");
     FA_LDS_DECL
     cplx *lds = (cplx *)FA_LDS_PTR;
-    cplx *tails = lds + (size_t)((DB || FA_MULTI_PAIR2) ? 2 : 1) * T * R;
+    cplx *tails = lds + (size_t)((DB != 0) ? 2 : 1) * T * R;
     unsigned long long *mx = (unsigned long long *)(tails + (size_t)2 * 2 * P0);
     cplx *twl = (cplx *)(mx + ((BF + 1) & ~1));
     constexpr int kTwTotal = N0 * ((1 << STAGES) - 1);
@@ -1478,6 +1476,28 @@ template <int N2, int R, int NE> FA_DEV void body_mid(const BigLevel &G)
     else pair_product_core_sym<N2, R, 1, true, true>(io, lds, tw, G.L.kappa);
 }
 
+// loads of the right factor's two rows, FA_MID_BSTEP elements per barrier interval of the left factor's
+// transforms (fft_wg2 hook)
+#ifndef FA_MID_BSTEP
+#define FA_MID_BSTEP 2
+#endif
+template <int N2, int R> struct MidBLoader {
+    const cplx *p0, *p1;
+    int rows, row, v;
+    cplx (&b11)[R];
+    cplx (&b21)[R];
+    FA_DEV void operator()(int k) const
+    {
+#pragma unroll
+        for (int i = 0; i < R; i++)
+            if (i / FA_MID_BSTEP == k) {
+                const size_t o = yz_index(rows, N2, row, v + (N2 / R) * i);
+                b11[i] = p0[o];
+                b21[i] = p1[o];
+            }
+    }
+};
+
 // Row step of the symmetric form, written for memory-level parallelism: the row pointers of the four
 // input polynomials are formed without branches, all 4*R (DIRECT: 2 x 4*R) 16-byte loads of the lane
 // are issued back to back before anything consumes them (the generic IO object above branches per
@@ -1507,6 +1527,7 @@ template <int N2, int R, bool DIRECT> FA_DEV void body_mid_sym(const BigLevel &G
     }
     const long long mA = 2 * P, mB = 2 * P + 1;
     cplx a11[R], a21[R], b11[R], b21[R];
+    MidBLoader<N2, R> bld{nullptr, nullptr, 0, 0, 0, b11, b21};
     // One level is one round of resident workgroups (two per CU), which all start together and then
     // sit in the same phase -- everybody loading (HBM saturated, vector units idle), then everybody
     // transforming (vector units saturated, HBM idle).  Holding back the second half of the grid -- the
@@ -1555,11 +1576,10 @@ template <int N2, int R, bool DIRECT> FA_DEV void body_mid_sym(const BigLevel &G
             const size_t o = yz_index(rows, N2, row, v + (N2 / R) * i);
             a11[i] = pA0[o]; a21[i] = pA1[o];
         }
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-            const size_t o = yz_index(rows, N2, row, v + (N2 / R) * i);
-            b11[i] = pB0[o]; b21[i] = pB1[o];
-        }
+        // the right factor's rows are requested from inside the left factor's transforms (MidBLoader):
+        // a wave cannot run ahead of a load it has not been able to issue yet, and with all 4*R requests of
+        // every wave queued at once the first transform starts only when the whole level has been fetched
+        bld.p0 = pB0; bld.p1 = pB1; bld.rows = rows; bld.row = row; bld.v = v;
     }
     FA_STAMP(G.stamps, 1);
     // ---- bookkeeping of the level (once per pair) and the factors every polynomial shares ------------
@@ -1588,7 +1608,8 @@ template <int N2, int R, bool DIRECT> FA_DEV void body_mid_sym(const BigLevel &G
     // ---- transforms and product -----------------------------------------------------------------------
     const cplx *tw = G.tw2;
     FA_STAMP(G.stamps, 2);
-    fft_wg2<N2, R, 1, -1, true>(a11, a21, lds, v, 0, tw);
+    if constexpr (DIRECT) fft_wg2<N2, R, 1, -1, true>(a11, a21, lds, v, 0, tw);
+    else fft_wg2<N2, R, 1, -1, true>(a11, a21, lds, v, 0, tw, bld);
     FA_STAMP(G.stamps, 3);
 #pragma unroll
     for (int i = 0; i < R; i++) {
