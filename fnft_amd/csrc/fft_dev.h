@@ -270,14 +270,38 @@ FA_DEV void fft_wg(cplx (&x)[R], cplx *lds, int v, int c, const cplx *__restrict
 // W_X(p+1) follows the barrier that follows R_X(p) of every lane; W_Y(p) follows the barrier that
 // follows R_Y(p-1) of every lane.
 // ---------------------------------------------------------------------------------------------
+// twiddles of one radix-8 pass of a lane (w, w^2, w^4 of its butterfly; the other powers by
+// multiplication): both sequences of a pair-interleaved transform use the same set, and the set of the
+// NEXT pass is requested one barrier interval ahead, before the caller's hook issues its own loads --
+// so that waiting for twiddles never waits for the hook's (younger) loads
+struct TwSet8 {
+    cplx w1, w2, w4;
+};
+
 template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2Pass {
     static constexpr int r = (NCUR < R) ? NCUR : R;
     static constexpr int J = R / r;
     static constexpr bool last = (NCUR == r);
+    // one shared, prefetched twiddle set per pass: radix-8 passes of one butterfly per lane with the table in L2
+    static constexpr bool kShared = TWC && r == 8 && J == 1 && !last;
+
+    static FA_DEV TwSet8 load_tw(int v, const cplx *__restrict__ tw)
+    {
+        TwSet8 t;
+        if constexpr (kShared) {
+            const int p = v / S;
+            t.w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
+            t.w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
+            t.w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+        } else {
+            t.w1 = t.w2 = t.w4 = cmake(1.0, 0.0);
+        }
+        return t;
+    }
 
     // radix-r butterflies (and twiddles, unless this is the last pass) of one sequence, in place:
     // butterfly j's output k is left in x[j + J*k]
-    static FA_DEV void bfly(cplx (&x)[R], int v, const cplx *__restrict__ tw)
+    static FA_DEV void bfly(cplx (&x)[R], int v, const cplx *__restrict__ tw, const TwSet8 &ts)
     {
 #pragma unroll
         for (int j = 0; j < J; j++) {
@@ -288,7 +312,13 @@ template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2P
             for (int k = 0; k < r; k++) t[k] = x[j + J * k];
             RegDft<r, SIGN>::run(t);
             if constexpr (!last) {
-                if constexpr (TWC && r == 8) {
+                if constexpr (kShared) {
+                    t[4] = t[4] * ts.w4; t[5] = t[5] * ts.w4; t[6] = t[6] * ts.w4; t[7] = t[7] * ts.w4;
+                    t[1] = t[1] * ts.w1; t[5] = t[5] * ts.w1;
+                    t[2] = t[2] * ts.w2; t[6] = t[6] * ts.w2;
+                    const cplx w3 = ts.w1 * ts.w2;
+                    t[3] = t[3] * w3; t[7] = t[7] * w3;
+                } else if constexpr (TWC && r == 8) {
                     const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
                     const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
                     const cplx w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
@@ -333,36 +363,40 @@ template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2P
         for (int i = 0; i < R; i++) x[i] = buf[(size_t)lds_swz<N>(v + (N / R) * i) * B + c];
     }
 
-    // entered with X's pass-p inputs in registers and Y's pass-p inputs READ ISSUED (or, for the
-    // first pass, in registers).  hook(k) is called once per barrier interval, k = 0, 1, 2, ... (two per
-    // pass): the caller's chance to put independent work -- global loads of the NEXT operands -- into
-    // the instruction stream of this transform.
+    // entered with X's pass-p inputs in registers, Y's pass-p inputs READ ISSUED (or, for the first
+    // pass, in registers) and this pass's shared twiddle set requested (ts).  hook(k) is called once per
+    // barrier interval, k = 0, 1, 2, ... (two per pass): the caller's chance to put independent work --
+    // global loads of the NEXT operands -- into the instruction stream of this transform.
     template <class Hook>
     static FA_DEV void run(cplx (&x)[R], cplx (&y)[R], cplx *bufX, cplx *bufY, int v, int c,
-                           const cplx *__restrict__ tw, Hook &hook, int k0)
+                           const cplx *__restrict__ tw, Hook &hook, int k0, const TwSet8 &ts)
     {
-        bfly(x, v, tw);
+        using Next = Fft2Pass<N, R, B, SIGN, NCUR / r, S * r, TWC>;
+        bfly(x, v, tw, ts);
         if constexpr (last) {
             hook(k0);
-            bfly(y, v, tw);
+            bfly(y, v, tw, ts);
             hook(k0 + 1);
         } else {
             write(x, bufX, v, c);
+            const TwSet8 tn = Next::load_tw(v, tw);   // next pass's set: older than the hook's loads
             hook(k0);
             FA_SYNC_LDS();
             read(x, bufX, v, c);
-            bfly(y, v, tw);
+            bfly(y, v, tw, ts);
             write(y, bufY, v, c);
             hook(k0 + 1);
             FA_SYNC_LDS();
             read(y, bufY, v, c);
-            Fft2Pass<N, R, B, SIGN, NCUR / r, S * r, TWC>::run(x, y, bufX, bufY, v, c, tw, hook, k0 + 2);
+            Next::run(x, y, bufX, bufY, v, c, tw, hook, k0 + 2, tn);
         }
     }
 };
 template <int N, int R, int B, int SIGN, int S, bool TWC> struct Fft2Pass<N, R, B, SIGN, 1, S, TWC> {
+    static FA_DEV TwSet8 load_tw(int, const cplx *__restrict__) { return TwSet8{cmake(1.0, 0.0), cmake(1.0, 0.0), cmake(1.0, 0.0)}; }
     template <class Hook>
-    static FA_DEV void run(cplx (&)[R], cplx (&)[R], cplx *, cplx *, int, int, const cplx *__restrict__, Hook &, int) {}
+    static FA_DEV void run(cplx (&)[R], cplx (&)[R], cplx *, cplx *, int, int, const cplx *__restrict__, Hook &, int,
+                           const TwSet8 &) {}
 };
 
 struct FftNoHook {
@@ -373,7 +407,9 @@ template <int N, int R, int B, int SIGN, bool TWC = false, class Hook>
 FA_DEV void fft_wg2(cplx (&x)[R], cplx (&y)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw, Hook &hook)
 {
     static_assert(N >= R, "fft_wg2: N must be at least R");
-    Fft2Pass<N, R, B, SIGN, N, 1, TWC>::run(x, y, lds, lds + (size_t)N * B, v, c, tw, hook, 0);
+    using P0 = Fft2Pass<N, R, B, SIGN, N, 1, TWC>;
+    const TwSet8 t0 = P0::load_tw(v, tw);
+    P0::run(x, y, lds, lds + (size_t)N * B, v, c, tw, hook, 0, t0);
 }
 template <int N, int R, int B, int SIGN, bool TWC = false>
 FA_DEV void fft_wg2(cplx (&x)[R], cplx (&y)[R], cplx *lds, int v, int c, const cplx *__restrict__ tw)

@@ -11,8 +11,9 @@ def disasm(lib=LIB):
     l2 = os.path.join(d, "lib.so")
     subprocess.check_call(["cp", lib, l2])
     subprocess.run([LLVM + "/llvm-objdump", "--offloading", l2], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
-    co = [f for f in os.listdir(d) if "gfx950" in f][0]
-    out = subprocess.run([LLVM + "/llvm-objdump", "-d", os.path.join(d, co)], stdout=subprocess.PIPE, text=True).stdout
+    out = ""
+    for co in sorted(f for f in os.listdir(d) if "gfx950" in f):   # one code object per translation unit
+        out += subprocess.run([LLVM + "/llvm-objdump", "-d", os.path.join(d, co)], stdout=subprocess.PIPE, text=True).stdout
     dm = subprocess.run(["c++filt"], input=out, stdout=subprocess.PIPE, text=True).stdout
     return dm
 

@@ -10,8 +10,9 @@ def resources(lib=LIB):
     l2 = os.path.join(d, "lib.so")
     subprocess.check_call(["cp", lib, l2])
     subprocess.run([LLVM + "/llvm-objdump", "--offloading", l2], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
-    co = [f for f in os.listdir(d) if "gfx950" in f][0]
-    notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", os.path.join(d, co)], stdout=subprocess.PIPE, text=True).stdout
+    notes = ""
+    for co in sorted(f for f in os.listdir(d) if "gfx950" in f):   # one code object per translation unit
+        notes += subprocess.run([LLVM + "/llvm-readelf", "--notes", os.path.join(d, co)], stdout=subprocess.PIPE, text=True).stdout
     out, cur = [], {}
     for line in notes.splitlines():
         m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
