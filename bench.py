@@ -181,11 +181,12 @@ def main():
     dq = torch.from_numpy(q_host).cuda()
     nout = 1 if cfg5 else 3   # fnft_kdvv returns the reflection coefficient only
     outs = [torch.zeros(B * nout * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
-    gather_bufs = None
-    if world > 1 and rank == 0 and args.gather != "none":
-        gather_bufs = [[torch.zeros(B * nout * M, 2, dtype=torch.float64,
-                                    device="cpu" if args.rehearse_gloo else "cuda") for _ in range(world)]
-                       for _ in range(2)]
+    # N > 1: the result shards meet on rank 0 through the product's sharding module (fnft_amd/sharding.py):
+    # device tensors into RCCL under nccl; under the gloo rehearsal the same calls stage through the host
+    gatherer = None
+    if world > 1 and args.gather != "none":
+        from fnft_amd import sharding
+        gatherer = sharding.ShardGather((B * nout * M, 2), torch.float64, dst=0, depth=2)
     stream = torch.cuda.current_stream().cuda_stream
 
     def transform(out_ptr):
@@ -196,19 +197,16 @@ def main():
 
     def one_step(i, pending, last=False):
         buf = outs[i % 2]
+        if gatherer is not None:
+            gatherer.reserve()   # the gather that read this buffer two steps ago has finished
         rc = transform(buf.data_ptr())
         if rc != 0:
             raise RuntimeError("fnft_amd_nsev_contspec_device rc=%d: %s" % (rc, capi.last_error()))
-        if world > 1 and (args.gather == "step" or (args.gather == "job" and last)):
-            # the buffer written two steps ago must have been gathered before it is reused
-            if len(pending) >= 2:
-                pending.pop(0).wait()
-            src = torch.view_as_real(buf)
+        if gatherer is not None and (args.gather == "step" or (args.gather == "job" and last)):
             if args.rehearse_gloo:
-                torch.cuda.synchronize()
-                src = src.cpu()
-            w = dist.gather(src, gather_bufs[i % 2] if rank == 0 else None, dst=0, async_op=True)
-            pending.append(w)
+                torch.cuda.synchronize()   # gloo copies through the host: the kernels must have finished
+            # nccl: the collective is ordered behind this step's kernels (same current stream)
+            gatherer.start(torch.view_as_real(buf), i)
 
     def barrier():
         torch.cuda.synchronize()
@@ -219,8 +217,8 @@ def main():
     pending = []
     for i in range(args.warmup):
         one_step(i, pending, last=(i == args.warmup - 1))
-    for w in pending:
-        w.wait()
+    if gatherer is not None:
+        gatherer.wait()
     pending = []
     rc = plan.finish(stream)
     if rc != 0:
@@ -233,8 +231,8 @@ def main():
     ev0.record()
     for i in range(args.steps):
         one_step(i, pending, last=(i == args.steps - 1))
-    for w in pending:
-        w.wait()
+    if gatherer is not None:
+        gatherer.wait()
     ev1.record()
     barrier()
     t1 = time.perf_counter()

@@ -76,6 +76,7 @@ EXPORTED = [
     "fnft_amd_plan_workspace_bytes", "fnft_amd_nsev_contspec_device", "fnft_amd_plan_finish",
     "fnft_amd_plan_last_ms", "fnft_amd_plan_set_timing", "fnft_amd_plan_set_launch_timing",
     "fnft_amd_plan_launch_count", "fnft_amd_plan_launch_ms", "fnft_amd_plan_get_transfer_matrix",
+    "fnft_amd_plan_get_transfer_matrix_device", "fnft_amd_plan_device", "fnft_amd_current_device",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -164,6 +165,11 @@ def load(path=None):
     L.fnft_amd_plan_launch_ms.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_size_t]
     L.fnft_amd_plan_get_transfer_matrix.restype = i32
     L.fnft_amd_plan_get_transfer_matrix.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(i32)]
+    L.fnft_amd_plan_get_transfer_matrix_device.restype = i32
+    L.fnft_amd_plan_get_transfer_matrix_device.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(i32), vp]
+    L.fnft_amd_plan_device.restype = C.c_int
+    L.fnft_amd_plan_device.argtypes = [vp]
+    L.fnft_amd_current_device.restype = C.c_int
     if path is None:
         _lib = L
     return L
@@ -469,6 +475,18 @@ class Plan:
 
     def finish(self, stream=0):
         return int(self.L.fnft_amd_plan_finish(self.h, C.c_void_p(stream)))
+
+    def transfer_matrix_device(self, out_ptr, b=0, stream=0):
+        """Transfer matrix of signal b into a device buffer of 4*(deg+1) complex128; returns (rc, deg, W)."""
+        deg = C.c_size_t(0)
+        W = C.c_int32(0)
+        rc = self.L.fnft_amd_plan_get_transfer_matrix_device(self.h, b, C.c_void_p(out_ptr), C.byref(deg), C.byref(W),
+                                                             C.c_void_p(stream))
+        return int(rc), int(deg.value), int(W.value)
+
+    @property
+    def device(self):
+        return int(self.L.fnft_amd_plan_device(self.h))
 
     def transfer_matrix(self, b=0):
         deg = C.c_size_t(0)

@@ -331,6 +331,30 @@ FNFT_INT fnft_amd_plan_get_transfer_matrix(fnft_amd_plan_t *plan, FNFT_UINT b,
     return rc;
 }
 
+// Device variant: the transfer matrix of signal b goes to a DEVICE buffer of 4*(deg+1) complex128 (same layout),
+// enqueued on `stream`; *deg and *W are returned to the host (this call waits for the stream: W is read back).
+FNFT_INT fnft_amd_plan_get_transfer_matrix_device(fnft_amd_plan_t *plan, FNFT_UINT b, void *d_result,
+                                                  FNFT_UINT *deg, FNFT_INT *W, void *stream)
+{
+    if (!plan || !d_result || !plan->pl->tree_valid || b >= plan->pl->batch) return FNFT_EC_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(plan->mtx);
+    DeviceGuard dg(plan->device);
+    if (!dg.ok) return FNFT_EC_OTHER;
+    Plan &pl = *plan->pl;
+    plan->be.stream = (hipStream_t)stream;
+    pl.export_tm();
+    const size_t per = 4 * (pl.res_deg + 1);
+    if (!hip_ok(hipMemcpyAsync(d_result, pl.tm_out + b * per, per * sizeof(cplx), hipMemcpyDeviceToDevice,
+                               plan->be.stream), "hipMemcpyAsync(D2D)"))
+        return FNFT_EC_OTHER;
+    int w = 0;
+    plan->be.d2h(&w, pl.wexp[pl.cur] + b, sizeof(int));
+    const int rc = plan->be.sync();
+    if (deg) *deg = pl.res_deg;
+    if (W) *W = w;
+    return rc;
+}
+
 // ---- section 2: private-layer seam, host buffers ----------------------------------------------
 
 FNFT_UINT fnft__poly_fmult2x2_numel(const FNFT_UINT deg, const FNFT_UINT n)

@@ -281,6 +281,12 @@ double fnft_amd_plan_launch_ms(const fnft_amd_plan_t *plan, FNFT_UINT i, char *n
 FNFT_INT fnft_amd_plan_get_transfer_matrix(fnft_amd_plan_t *plan, FNFT_UINT b,
                                            FNFT_COMPLEX *result_host, FNFT_UINT *deg,
                                            FNFT_INT *W);
+/* Same, into a DEVICE buffer of 4*(D*deg0+1) complex128 (device-to-device, no host staging of the
+ * coefficients; the multi-GPU sample-axis split gathers these buffers over RCCL).  *deg, *W come back to
+ * the host, so the call waits for `stream`.  A plan made with M = 0 and a call of
+ * fnft_amd_nsev_contspec_device with d_contspec = NULL computes the transfer matrix only. */
+FNFT_INT fnft_amd_plan_get_transfer_matrix_device(fnft_amd_plan_t *plan, FNFT_UINT b, void *d_result,
+                                                  FNFT_UINT *deg, FNFT_INT *W, void *stream);
 
 /* ======================================================================================== */
 /* 4. Korteweg-de Vries equation, vanishing boundaries (include/fnft_kdvv.h)                  */

@@ -184,3 +184,45 @@ def test_sample_axis_sharding(world, D, disc, deg0):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(results)
+
+
+# ---- per-step gather with persistent buffers (what bench.py --gpus N runs every step) --------------
+def _gatherer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = sharding.ShardGather((6, 2), torch.float64, dst=0, depth=2)
+        assert sharding.wire_device() == torch.device("cpu")
+        ok = True
+        bufs = [torch.zeros(6, 2, dtype=torch.float64) for _ in range(2)]
+        for step in range(5):
+            g.reserve()                                   # buffer step % 2 may be overwritten now
+            bufs[step % 2].fill_(float(100 * step + rank))
+            g.start(bufs[step % 2], step)
+            if step >= 1 and rank == 0:                   # step - 1 has been gathered once two are in flight
+                g.reserve()
+                got = g.result(step - 1)
+                ok = ok and all(float(got[r][0, 0]) == 100 * (step - 1) + r for r in range(world))
+        g.wait()
+        if rank == 0:
+            got = g.result(4)
+            ok = ok and all(float(got[r][3, 1]) == 400 + r for r in range(world))
+        q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_gather_per_step():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results)
