@@ -77,6 +77,8 @@ EXPORTED = [
     "fnft_amd_plan_last_ms", "fnft_amd_plan_set_timing", "fnft_amd_plan_set_launch_timing",
     "fnft_amd_plan_launch_count", "fnft_amd_plan_launch_ms", "fnft_amd_plan_get_transfer_matrix",
     "fnft_amd_plan_get_transfer_matrix_device", "fnft_amd_plan_device", "fnft_amd_current_device",
+    "fnft_amd_nsev_contspec_from_tm_device", "fnft__misc_resample", "fnft__poly_roots_fasteigen",
+    "fnft__nse_scatter_bound_states",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -167,6 +169,14 @@ def load(path=None):
     L.fnft_amd_plan_get_transfer_matrix.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(i32)]
     L.fnft_amd_plan_get_transfer_matrix_device.restype = i32
     L.fnft_amd_plan_get_transfer_matrix_device.argtypes = [vp, sz, vp, C.POINTER(sz), C.POINTER(i32), vp]
+    L.fnft_amd_nsev_contspec_from_tm_device.restype = i32
+    L.fnft_amd_nsev_contspec_from_tm_device.argtypes = [vp, vp, i32, vp, C.POINTER(dbl), C.POINTER(dbl), C.c_int, vp]
+    L.fnft__misc_resample.restype = i32
+    L.fnft__misc_resample.argtypes = [sz, dbl, vp, dbl, vp]
+    L.fnft__poly_roots_fasteigen.restype = i32
+    L.fnft__poly_roots_fasteigen.argtypes = [sz, vp, vp]
+    L.fnft__nse_scatter_bound_states.restype = i32
+    L.fnft__nse_scatter_bound_states.argtypes = [sz, vp, vp, vp, sz, vp, vp, vp, vp, C.c_int, sz]
     L.fnft_amd_plan_device.restype = C.c_int
     L.fnft_amd_plan_device.argtypes = [vp]
     L.fnft_amd_current_device.restype = C.c_int
@@ -275,6 +285,38 @@ def fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="SUBSAMPLE_AND_REFINE", 
     res = nc[k:2 * k] if d == 2 else (nc[:k] if d == 1 else None)
     out = (int(rc), bs[:k].copy(), None if ncs is None else ncs.copy(), None if res is None else res.copy())
     return out + ((cs,) if M > 0 else ())
+
+
+def misc_resample(q, eps_t, delta):
+    """fnft__misc_resample: (rc, q shifted by delta on the band-limited periodic grid)."""
+    L = load()
+    q = _c128(q)
+    out = np.zeros(q.size, np.complex128)
+    rc = L.fnft__misc_resample(q.size, float(eps_t), _ptr(q), float(delta), _ptr(out))
+    return int(rc), out
+
+
+def poly_roots_fasteigen(p):
+    """fnft__poly_roots_fasteigen: p highest power first -> (rc, roots[deg])."""
+    L = load()
+    p = _c128(p)
+    roots = np.zeros(max(p.size - 1, 1), np.complex128)
+    rc = L.fnft__poly_roots_fasteigen(p.size - 1, _ptr(p), _ptr(roots))
+    return int(rc), roots[: p.size - 1]
+
+
+def nse_scatter_bound_states(q, T, lam, skip_b=False, discretization="BO"):
+    """fnft__nse_scatter_bound_states: (rc, a, a', b) at the points lam."""
+    L = load()
+    q = _c128(q)
+    lam = _c128(lam)
+    Tn = np.ascontiguousarray(T, np.float64)
+    K = lam.size
+    a, ap, b = (np.zeros(max(K, 1), np.complex128) for _ in range(3))
+    d = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    rc = L.fnft__nse_scatter_bound_states(q.size, _ptr(q), None, _ptr(Tn), K, _ptr(lam), _ptr(a), _ptr(ap), _ptr(b), d,
+                                          1 if skip_b else 0)
+    return int(rc), a[:K], ap[:K], b[:K]
 
 
 def poly_fmult2x2(deg, n, p, normalize=True):
@@ -475,6 +517,12 @@ class Plan:
 
     def finish(self, stream=0):
         return int(self.L.fnft_amd_plan_finish(self.h, C.c_void_p(stream)))
+
+    def contspec_from_tm_device(self, tm_ptr, W, out_ptr, T, XI, contspec_type="BOTH", stream=0):
+        """Continuous spectrum from a transfer matrix in device memory (fnft_amd_nsev_contspec_from_tm_device)."""
+        c = CSTYPE[contspec_type] if isinstance(contspec_type, str) else int(contspec_type)
+        return int(self.L.fnft_amd_nsev_contspec_from_tm_device(self.h, C.c_void_p(tm_ptr), int(W), C.c_void_p(out_ptr),
+                                                                _d2(T), _d2(XI), c, C.c_void_p(stream)))
 
     def transfer_matrix_device(self, out_ptr, b=0, stream=0):
         """Transfer matrix of signal b into a device buffer of 4*(deg+1) complex128; returns (rc, deg, W)."""

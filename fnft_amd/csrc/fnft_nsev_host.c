@@ -291,11 +291,19 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
                                                 (int)opts->discspec_type, (int)opts->discretization,
                                                 opts->richardson_extrapolation_flag == 1, K_ptr, bound_states,
                                                 normconsts_or_residues, &warn);
-        if (warn) {
+        if (warn & 1) {
             fnft_printf_ptr_t p = fnft_errwarn_getprintf();
             if (p != NULL)
                 p("FNFT Warning: %s\n in %s(%i)-%d.%d.%d%s\n",
                   "Found more than *K_ptr bound states. Returning as many as possible.", __func__, __LINE__,
+                  FNFT_AMD_IFACE_MAJOR, FNFT_AMD_IFACE_MINOR, FNFT_AMD_IFACE_PATCH, FNFT_AMD_IFACE_SUFFIX);
+        }
+        if (warn & 2) {
+            fnft_printf_ptr_t p = fnft_errwarn_getprintf();
+            if (p != NULL)
+                p("FNFT Warning: %s\n in %s(%i)-%d.%d.%d%s\n",
+                  "Root finder stopped at its iteration limit; bound states may be inaccurate (clustered roots?).",
+                  __func__, __LINE__,
                   FNFT_AMD_IFACE_MAJOR, FNFT_AMD_IFACE_MINOR, FNFT_AMD_IFACE_PATCH, FNFT_AMD_IFACE_SUFFIX);
         }
         if (ret_code != FNFT_SUCCESS) {

@@ -249,6 +249,31 @@ FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, v
     return rc;
 }
 
+// nsev_compute_contspec (src/fnft_nsev.c:744-891) on a caller-supplied transfer matrix in device memory
+FNFT_INT fnft_amd_nsev_contspec_from_tm_device(fnft_amd_plan_t *plan, const void *d_tm, FNFT_INT W, void *d_contspec,
+                                               const FNFT_REAL *T, const FNFT_REAL *XI,
+                                               fnft_nsev_cstype_t contspec_type, void *stream)
+{
+    if (!plan || plan->kdv_disc >= 0 || !d_tm || !d_contspec || !T || !(T[0] < T[1]) || !XI || !(XI[0] < XI[1]))
+        return FNFT_EC_INVALID_ARGUMENT;
+    const int cst = (int)contspec_type;
+    if (cst < 0 || cst > 2 || plan->pl->M == 0) return FNFT_EC_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(plan->mtx);
+    DeviceGuard dg(plan->device);
+    if (!dg.ok) return FNFT_EC_OTHER;
+    Plan &pl = *plan->pl;
+    plan->be.stream = (hipStream_t)stream;
+    plan->be.failed = false;
+    Plan::Contspec cs;
+    cs.T[0] = T[0]; cs.T[1] = T[1]; cs.XI[0] = XI[0]; cs.XI[1] = XI[1];
+    cs.nse_disc = plan->nse_disc;
+    cs.cstype = cst;
+    cs.normalization_flag = 1;
+    const int rc = pl.run_contspec_tm(d_contspec, cs, d_tm, (int)W);
+    if (plan->be.failed) return FNFT_EC_OTHER;
+    return rc;
+}
+
 // ---- KdV ----------------------------------------------------------------------------------------
 FNFT_INT fnft_amd_kdvv_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
                                    fnft_kdv_discretization_t discretization, int device)
@@ -388,6 +413,73 @@ FNFT_INT fnft__poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, con
     return fnft_amd_poly_chirpz(deg, p, a, w, M, result);
 }
 
+// include/private/fnft__misc.h:241-242 (src/private/fnft__misc.c:326-407): band-limited shift by delta
+FNFT_INT fnft__misc_resample(const FNFT_UINT D, const FNFT_REAL eps_t, FNFT_COMPLEX const *const q,
+                             const FNFT_REAL delta, FNFT_COMPLEX *const q_new)
+{
+    // argument checks of the reference, :331-338
+    if (D <= 2 || !q || !q_new || eps_t == 0.0) return FNFT_EC_INVALID_ARGUMENT;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    return Plan::resample_host(be, D, eps_t, q, delta, q_new);
+}
+
+// include/private/fnft__poly_roots_fasteigen.h (src/private/fnft__poly_roots_fasteigen.c:29-48): all roots of
+// p[0] z^deg + ... + p[deg].  The reference calls eiscor's QR (Fortran); here the Ehrlich-Aberth kernels.
+FNFT_INT fnft__poly_roots_fasteigen(const FNFT_UINT deg, FNFT_COMPLEX const *const p, FNFT_COMPLEX *const roots)
+{
+    if (!p || !roots) return FNFT_EC_INVALID_ARGUMENT;
+    if (deg == 0) return FNFT_SUCCESS;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    NftDiscSpec<HipBackend> ds(be);
+    cplx *d_coef = (cplx *)be.alloc((deg + 1) * sizeof(cplx));
+    if (!d_coef) return FNFT_EC_NOMEM;
+    be.h2d(d_coef, p, (deg + 1) * sizeof(cplx));
+    std::vector<std::complex<double>> z;
+    int rc = ds.roots(d_coef, deg, z);
+    be.free(d_coef);
+    if (be.failed) return FNFT_EC_OTHER;
+    if (rc != NFT_SUCCESS) return -abs(rc);   // E_SUBROUTINE, :44-47
+    for (size_t i = 0; i < deg; i++) roots[i] = z[i];
+    return FNFT_SUCCESS;
+}
+
+// include/private/fnft__nse_scatter.h:76-80 (src/private/fnft__nse_scatter_bound_states.c:29-667) for the
+// Boffetta-Osborne scheme (the one fnft_nsev uses for Newton refinement and norming constants of every
+// 2SPLIT discretization): a, a' and b = phi/psi at K points lambda; q holds the D samples, r is not read
+// (r = -conj(q)).  Chunk-parallel on the GPU (body_bs_*).
+FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *const q, FNFT_COMPLEX *r,
+                                        FNFT_REAL const *const T, FNFT_UINT K, FNFT_COMPLEX *bound_states,
+                                        FNFT_COMPLEX *a_vals, FNFT_COMPLEX *aprime_vals, FNFT_COMPLEX *b,
+                                        fnft_nse_discretization_t discretization, FNFT_UINT skip_b_flag)
+{
+    (void)r;
+    // argument checks in the reference's order, :53-66
+    if (D == 0 || !q || !T || K == 0 || !bound_states || !a_vals || !aprime_vals) return FNFT_EC_INVALID_ARGUMENT;
+    if (!skip_b_flag && !b) return FNFT_EC_INVALID_ARGUMENT;
+    if (discretization != fnft_nse_discretization_BO) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    if (D < 2 || !(T[0] < T[1])) return FNFT_EC_INVALID_ARGUMENT;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    NftDiscSpec<HipBackend> ds(be);
+    NftDiscSpec<HipBackend>::Prepared P;
+    // any 2SPLIT scheme: upsampling factor 1, the slow scatterer is BO (src/fnft_nsev.c:675-680)
+    int rc = ds.prepare(D, (const std::complex<double> *)q, T, D, (int)fnft_nse_discretization_2SPLIT4B, P);
+    if (rc == NFT_SUCCESS)
+        rc = ds.scatter(P, K, (const std::complex<double> *)bound_states, (std::complex<double> *)a_vals,
+                        (std::complex<double> *)aprime_vals, (std::complex<double> *)b, skip_b_flag != 0);
+    ds.release(P);
+    if (be.failed) return FNFT_EC_OTHER;
+    return rc;
+}
+
 FNFT_UINT fnft__akns_fscatter_numel(FNFT_UINT D, fnft__akns_discretization_t discretization)
 {
     const int deg = nft_akns_degree((int)discretization);
@@ -515,7 +607,7 @@ FNFT_INT fnft_amd__nsev_discspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
     size_t K = *K_ptr;
     const int rc = ds.run(D, (const std::complex<double> *)q, T, o, &K, (std::complex<double> *)bound_states,
                           (std::complex<double> *)normconsts_or_residues);
-    if (warn) *warn = ds.warn_more_than_K;
+    if (warn) *warn = (ds.warn_more_than_K ? 1 : 0) | (ds.warn_roots_unconverged ? 2 : 0);
     if (be.failed) return FNFT_EC_OTHER;
     if (rc == NFT_SUCCESS) *K_ptr = K;
     return rc;

@@ -72,7 +72,7 @@ struct KBsPick {
 struct KAberthNewton {
     using Params = AberthParams;
     static constexpr int THREADS = 64;
-    static constexpr size_t lds_bytes() { return 2 * 1024 * sizeof(cplx); }
+    static constexpr size_t lds_bytes() { return 2 * 1024 * (sizeof(cplx) + sizeof(double)); }
     static FA_DEV void body(const Params &p) { body_aberth_newton<1024>(p); }
 };
 struct KAberthUpdate {

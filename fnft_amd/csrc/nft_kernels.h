@@ -1952,6 +1952,7 @@ struct ChirpParams {
     const cplx *tail;
     const double *scale;
     const cplx *poly;    // explicit polynomial(s): npoly * (deg+1), highest first, or NULL
+    int poly_tm;         // poly holds whole transfer matrices (4 entries of deg+1 per signal); entry[] picks two
     size_t plane;
     long long deg_tot;   // Dpad*deg0 (tree layout)
     long long deg;       // polynomial degree actually evaluated
@@ -2032,6 +2033,8 @@ template <bool DFT> FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int
     // coefficient k (highest power first) of polynomial `slot` of signal b
     if (DFT)
         return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)(C.deg - k)];
+    if (C.poly && C.poly_tm)   // transfer matrices in the reference layout [r11|r12|r21|r22] per signal
+        return C.poly[((size_t)b * 4 + C.entry[slot]) * (size_t)(C.deg + 1) + (size_t)k];
     if (C.poly) return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)k];
     return stored_coef(C.body, C.tail, C.plane, C.deg_tot, C.deg, C.batch, C.ne, C.entry[slot], b, k)
            * C.scale[b];
@@ -2509,7 +2512,8 @@ FA_DEV void body_bs_pick(const BsParams &P)
 struct AberthParams {
     const cplx *coef;    // n+1 coefficients, highest power first
     long long n;
-    cplx *z;             // n estimates
+    const cplx *z;       // n estimates of this sweep (read by every workgroup)
+    cplx *z_out;         // the next sweep's estimates (double buffer: no workgroup reads what another one writes)
     cplx *w;             // n Newton corrections
     unsigned long long *maxcorr;   // bits of max |corr|/|z| of the sweep
 };
@@ -2521,6 +2525,7 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
 {
     FA_LDS_DECL
     cplx *tile = (cplx *)FA_LDS_PTR;
+    double *tabs = (double *)(tile + 2 * TILE);   // |coefficient| of the same tile, both orientations
     const long long k = (long long)FA_BID * FA_BDIM + FA_TID;
     const long long n = P.n;
     const bool act = k < n;
@@ -2528,7 +2533,9 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
     const bool inside = cnorm2(z) <= 1.0;
     const cplx x = inside ? z : c_div(cmake(1.0, 0.0), z);
     const cplx x2 = x * x, w = x2 * x2;
+    const double ax = sqrt(cnorm2(x)), aw = (ax * ax) * (ax * ax);
     cplx p0 = cmake(0.0, 0.0), p1 = p0, p2 = p0, p3 = p0, d0 = p0, d1 = p0, d2 = p0, d3 = p0;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;   // the same four chains on |coefficients| and |x|: error scale
     // powers run from the top block (m = Mtop) down to m = 0; block m holds powers 4m .. 4m+3
     const long long Mtop = n / 4;
     for (long long mhi = Mtop; mhi >= 0; mhi -= TILE / 4) {
@@ -2538,8 +2545,12 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
         for (int t = FA_TID; t < TILE; t += FA_BDIM) {
             const long long kk = kbase + t;
             // both orientations are needed inside one workgroup: interleave them
-            tile[2 * t] = (kk <= n) ? P.coef[n - kk] : cmake(0.0, 0.0);
-            tile[2 * t + 1] = (kk <= n) ? P.coef[kk] : cmake(0.0, 0.0);
+            const cplx ca = (kk <= n) ? P.coef[n - kk] : cmake(0.0, 0.0);
+            const cplx cb = (kk <= n) ? P.coef[kk] : cmake(0.0, 0.0);
+            tile[2 * t] = ca;
+            tile[2 * t + 1] = cb;
+            tabs[2 * t] = sqrt(cnorm2(ca));
+            tabs[2 * t + 1] = sqrt(cnorm2(cb));
         }
         FA_SYNC();
         const int off = inside ? 0 : 1;
@@ -2549,6 +2560,10 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
             d1 = d1 * w + p1; p1 = p1 * w + tile[2 * (t + 1) + off];
             d2 = d2 * w + p2; p2 = p2 * w + tile[2 * (t + 2) + off];
             d3 = d3 * w + p3; p3 = p3 * w + tile[2 * (t + 3) + off];
+            e0 = fma(e0, aw, tabs[2 * t + off]);
+            e1 = fma(e1, aw, tabs[2 * (t + 1) + off]);
+            e2 = fma(e2, aw, tabs[2 * (t + 2) + off]);
+            e3 = fma(e3, aw, tabs[2 * (t + 3) + off]);
         }
     }
     if (!act) return;
@@ -2557,8 +2572,15 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
     const cplx p = p0 + x * p1 + x2 * p2 + x3 * p3;
     const cplx dsum = d0 + x * d1 + x2 * d2 + x3 * d3;
     const cplx dp = p1 + (x * p2) * 2.0 + (x2 * p3) * 3.0 + (x3 * dsum) * 4.0;
+    // |p(x)| at the level of its own evaluation error (running error bound of Horner's scheme, statistical
+    // sqrt(n) growth): the estimate is a root to working accuracy and is left alone -- without this, roots of
+    // an ill-conditioned polynomial keep receiving corrections of the size of the noise and never "converge"
+    const double escale = e0 + ax * (e1 + ax * (e2 + ax * e3));
+    const double noise = 2.220446049250313e-16 * (2.0 * sqrt((double)n) + 2.0) * escale;
     cplx wv;
-    if (inside) {
+    if (cnorm2(p) <= noise * noise) {
+        wv = cmake(0.0, 0.0);
+    } else if (inside) {
         wv = c_div(p, dp);
     } else {
         // p(z) = z^n q(y), y = 1/z:  p'/p = n/z - y^2 q'(y)/q(y)
@@ -2569,6 +2591,19 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
     P.w[k] = wv;
 }
 
+// distance vector for the Aberth sum with two repairs: the own term counts as 1/(1 + 0i) (taken out by the
+// caller), and an estimate that COINCIDES with another one -- 1/0 otherwise, after which both would freeze --
+// is treated as if it sat a tiny step away, in opposite directions for the two members of the pair
+FA_DEV cplx aberth_dist(cplx zk, cplx zj, long long k, long long j)
+{
+    if (j == k) return cmake(1.0, 0.0);
+    cplx d = zk - zj;
+    if (d.x == 0.0 && d.y == 0.0) {
+        const double h = 1.0e-8 * (1.0 + sqrt(cnorm2(zk)));
+        d = (k < j) ? cmake(h, 0.5 * h) : cmake(-h, -0.5 * h);
+    }
+    return d;
+}
 template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
 {
     FA_LDS_DECL
@@ -2583,20 +2618,17 @@ template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
         FA_SYNC();
         const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
         if (act) {
-            // 1/(zk - zj) = conj(d)/|d|^2; the own term is replaced by 1/(1 + 0i) and taken out below
+            // 1/(zk - zj) = conj(d)/|d|^2
             cplx s1 = cmake(0.0, 0.0);
             int j = 0;
             for (; j + 1 < lim; j += 2) {
-                cplx da = zk - tile[j], db = zk - tile[j + 1];
-                if (j0 + j == k) da = cmake(1.0, 0.0);
-                if (j0 + j + 1 == k) db = cmake(1.0, 0.0);
+                const cplx da = aberth_dist(zk, tile[j], k, j0 + j), db = aberth_dist(zk, tile[j + 1], k, j0 + j + 1);
                 const double ia = 1.0 / cnorm2(da), ib = 1.0 / cnorm2(db);
                 s = s + cmake(da.x * ia, -da.y * ia);
                 s1 = s1 + cmake(db.x * ib, -db.y * ib);
             }
             if (j < lim) {
-                cplx da = zk - tile[j];
-                if (j0 + j == k) da = cmake(1.0, 0.0);
+                const cplx da = aberth_dist(zk, tile[j], k, j0 + j);
                 const double ia = 1.0 / cnorm2(da);
                 s = s + cmake(da.x * ia, -da.y * ia);
             }
@@ -2609,9 +2641,15 @@ template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
     if (act) {
         const cplx w = P.w[k];
         cplx corr = c_div(w, cmake(1.0, 0.0) - w * s);
-        if (!(corr.x == corr.x) || !(corr.y == corr.y)) corr = cmake(0.0, 0.0);
+        const double az0 = sqrt(cnorm2(zk));
+        if (!(corr.x == corr.x) || !(corr.y == corr.y) || fabs(corr.x) > 1.0e300 || fabs(corr.y) > 1.0e300) {
+            // degenerate step (0/0, overflow): move the estimate a little instead of freezing it; the sweep
+            // then does not count as converged
+            const double h = 1.0e-6 * (1.0 + az0);
+            corr = cmake(h * (1.0 + (double)(k & 3)), -h * (1.0 + (double)((k >> 2) & 3)));
+        }
         const cplx zn = zk - corr;
-        P.z[k] = zn;
+        P.z_out[k] = zn;
         const double az = sqrt(cnorm2(zn));
         rel = sqrt(cnorm2(corr)) / (az > 1.0e-300 ? az : 1.0e-300);
     }

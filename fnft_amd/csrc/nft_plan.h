@@ -124,6 +124,7 @@ public:
     unsigned *max2[2] = {nullptr, nullptr};  // ping-pong across split levels, kMax2Slots per matrix
     int *wexp[2] = {nullptr, nullptr};  // per matrix, ping-pong with body/tail/scale
     int *status = nullptr;
+    int *wuser = nullptr;   // exponents of caller-supplied transfer matrices (run_contspec_tm)
     // monomial program of the order 5..8 schemes (nft_schemes.h), device copies
     double *prog_bfrac = nullptr, *prog_mw = nullptr;
     int *prog_ptr = nullptr;
@@ -285,7 +286,7 @@ public:
         be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
         be.free(chY); be.free(chV); be.free(chH); be.free(chVS); be.free(tm_out); be.free(twtab); be.free(twlo);
         be.free(prog_bfrac); be.free(prog_mw); be.free(prog_ptr); be.free(prog_fac);
-        be.free(rneg); be.free(dbg_stamps);
+        be.free(rneg); be.free(dbg_stamps); be.free(wuser);
         be.free(qpre); be.free(rsX); be.free(rsX12); be.free(rsQ12); be.free(rsY); be.free(rsV);
     }
 
@@ -603,7 +604,22 @@ public:
         C.jobs_per_group = 2;
     }
 
-    int run_contspec(void *d_contspec, const Contspec &cs)
+    int run_contspec(void *d_contspec, const Contspec &cs) { return run_contspec_impl(d_contspec, cs, nullptr, 0); }
+
+    // nsev_compute_contspec (src/fnft_nsev.c:744-891) on a transfer matrix the CALLER supplies: d_tm holds, per
+    // signal, [r11|r12|r21|r22] of deg+1 = D*deg0+1 coefficients each (highest power first, the layout of
+    // fnft__poly_fmult2x2 / fnft_amd_plan_get_transfer_matrix_device), true matrix = stored * 2^W.
+    int run_contspec_tm(void *d_contspec, const Contspec &cs, const void *d_tm, int W)
+    {
+        if (!d_tm) return NFT_EC_INVALID_ARGUMENT;
+        if (!wuser && !alloc(wuser, batch)) return NFT_EC_NOMEM;
+        std::vector<int> hw(batch, W);
+        be.h2d(wuser, hw.data(), batch * sizeof(int));
+        be.memset0(status, 4 * sizeof(int));
+        return run_contspec_impl(d_contspec, cs, (const cplx *)d_tm, 1);
+    }
+
+    int run_contspec_impl(void *d_contspec, const Contspec &cs, const cplx *d_tm, int from_tm)
     {
         // step size and phase factors refer to D_given = D/upsampling (fnft_nsev.c:766-774);
         // lambda -> z uses degree*upsampling (fnft__akns_discretization.c:204-219)
@@ -621,22 +637,23 @@ public:
         ChirpParams C;
         std::memset(&C, 0, sizeof(C));
         C.body = body[cur]; C.tail = tail[cur]; C.scale = scale[cur];
-        C.poly = nullptr;
+        C.poly = from_tm ? d_tm : nullptr;
+        C.poly_tm = from_tm;
         C.plane = plane;
         C.deg_tot = (long long)(Dpad * (size_t)deg0);
-        C.deg = (long long)res_deg;
+        C.deg = from_tm ? (long long)(D * (size_t)deg0) : (long long)res_deg;
         C.batch = (int)batch;
         C.npoly = 2;
-        C.ne = ne;
+        C.ne = from_tm ? 4 : ne;
         C.entry[0] = 0;                    // H11, fnft_nsev.c:829
-        C.entry[1] = (ne == 4) ? 2 : 1;    // H21, fnft_nsev.c:832 (plane 1 in the symmetric form)
+        C.entry[1] = (C.ne == 4) ? 2 : 1;  // H21, fnft_nsev.c:832 (plane 1 in the symmetric form)
         C.logA[0] = lA.real(); C.logA[1] = lA.imag();
         C.logW[0] = lV.real(); C.logW[1] = lV.imag();
         C.M = (long long)M;
         C.Ybuf = chY; C.Vbuf = chV; C.Hbuf = nullptr;
         fill_chirp_geometry(C, Lc);
         C.contspec = (cplx *)d_contspec;
-        C.W = wexp[cur];
+        C.W = from_tm ? wuser : wexp[cur];
         C.status = status;
         C.xi0 = cs.XI[0];
         C.eps_xi = eps_xi;
@@ -753,6 +770,66 @@ public:
             }
         }
         be.free(dp); be.free(dY); be.free(dV); be.free(dH); be.free(dstatus);
+        be.free(pl.twtab); be.free(pl.twlo);
+        return rc;
+    }
+
+    // stand-alone band-limited shift of one host signal by delta (fnft__misc.c:326-407): DFT of any length
+    // (chirp kernels in DFT mode), phase ramp exp(2 pi i delta f), inverse DFT, 1/D
+    static int resample_host(BE &be, size_t Dn, double eps_t, const std::complex<double> *q, double delta,
+                             std::complex<double> *q_new)
+    {
+        NftPlan pl(be, 2, 0, 1, 0, 1);  // only the twiddle tables of the plan are used
+        size_t L = nft_nextpow2(2 * Dn - 1);
+        if (L < 2 * (size_t)kRowChirp) L = 2 * (size_t)kRowChirp;
+        if (L > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
+        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, (size_t)1 << kFineLog2);
+        cplx *dq = nullptr, *dX = nullptr, *dX12 = nullptr, *dQ12 = nullptr, *dY = nullptr, *dV = nullptr;
+        int *dstatus = nullptr;
+        ok = ok && pl.alloc(dq, Dn) && pl.alloc(dX, Dn) && pl.alloc(dX12, 2 * Dn) && pl.alloc(dQ12, 2 * Dn)
+             && pl.alloc(dY, 2 * L) && pl.alloc(dV, L) && pl.alloc(dstatus, 4);
+        int rc = NFT_EC_NOMEM;
+        if (ok) {
+            pl.upload_twiddles();
+            be.h2d(dq, q, Dn * sizeof(cplx));
+            be.memset0(dstatus, 4 * sizeof(int));
+            ChirpParams C;
+            std::memset(&C, 0, sizeof(C));
+            C.poly = dq;
+            C.deg = (long long)Dn - 1;
+            C.batch = 1;
+            C.npoly = 1;
+            C.M = (long long)Dn;
+            C.Ybuf = dY; C.Vbuf = dV; C.Hbuf = dX;
+            pl.fill_chirp_geometry(C, L);
+            C.status = dstatus;
+            C.cstype = -1;
+            C.dft_len = (long long)Dn;
+            C.dft_sign = -1;
+            rc = pl.run_chirp(C);                                   // X = DFT(q), :366-370
+            if (rc == NFT_SUCCESS) {
+                ResampleParams R;
+                std::memset(&R, 0, sizeof(R));
+                R.X = dX; R.X12 = dX12; R.Q12 = dQ12; R.qpre = nullptr;
+                R.Din = (long long)Dn; R.Dsub = (long long)Dn; R.nskip = 1;
+                R.batch = 1;
+                R.delta_over_span = delta / ((double)Dn * eps_t);    // freq[i]*delta, :383-393
+                be.template run<KResamplePhase>((int)((Dn + 255) / 256), 1, R);
+                C.poly = dX12;
+                C.npoly = 2;
+                C.Hbuf = dQ12;
+                C.dft_sign = +1;
+                rc = pl.run_chirp(C);                               // inverse DFTs of the -delta and +delta copies
+            }
+            if (rc == NFT_SUCCESS) {
+                be.d2h(q_new, dQ12 + Dn, Dn * sizeof(cplx));        // the +delta copy
+                rc = be.sync();
+                const double inv = 1.0 / (double)Dn;                // :395-399
+                if (rc == NFT_SUCCESS)
+                    for (size_t i = 0; i < Dn; i++) q_new[i] *= inv;
+            }
+        }
+        be.free(dq); be.free(dX); be.free(dX12); be.free(dQ12); be.free(dY); be.free(dV); be.free(dstatus);
         be.free(pl.twtab); be.free(pl.twlo);
         return rc;
     }

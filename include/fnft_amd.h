@@ -197,6 +197,24 @@ FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p,
 FNFT_INT fnft__poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const FNFT_COMPLEX A,
                            const FNFT_COMPLEX W, const FNFT_UINT M, FNFT_COMPLEX *const result);
 
+/* include/private/fnft__misc.h:241-242 (src/private/fnft__misc.c:326-407): q_new = q shifted by delta on the
+ * periodically continued, band-limited grid (the 4SPLIT4A/B front end).  Host buffers of D samples, D > 2. */
+FNFT_INT fnft__misc_resample(const FNFT_UINT D, const FNFT_REAL eps_t, FNFT_COMPLEX const *const q,
+                             const FNFT_REAL delta, FNFT_COMPLEX *const q_new);
+
+/* include/private/fnft__poly_roots_fasteigen.h (src/private/fnft__poly_roots_fasteigen.c:29-48): the deg roots of
+ * p[0] z^deg + ... + p[deg] (host buffers), in no particular order.  The reference's Fortran QR (eiscor) is
+ * replaced by Ehrlich-Aberth sweeps on the GPU; failure to converge returns -FNFT_EC_OTHER as there. */
+FNFT_INT fnft__poly_roots_fasteigen(const FNFT_UINT deg, FNFT_COMPLEX const *const p, FNFT_COMPLEX *const roots);
+
+/* include/private/fnft__nse_scatter.h:76-80 (src/private/fnft__nse_scatter_bound_states.c:29-667), BO scheme:
+ * a(lambda_k), a'(lambda_k) and, unless skip_b_flag, b(lambda_k) for K points; q: D samples on [T0, T1], r is
+ * not read (r = -conj(q)).  Other schemes: FNFT_EC_NOT_YET_IMPLEMENTED. */
+FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *const q, FNFT_COMPLEX *r,
+                                        FNFT_REAL const *const T, FNFT_UINT K, FNFT_COMPLEX *bound_states,
+                                        FNFT_COMPLEX *a_vals, FNFT_COMPLEX *aprime_vals, FNFT_COMPLEX *b,
+                                        fnft_nse_discretization_t discretization, FNFT_UINT skip_b_flag);
+
 /* include/private/fnft__akns_fscatter.h:57,89-90 (src/private/fnft__akns_fscatter.c:34-42,64-925) */
 FNFT_UINT fnft__akns_fscatter_numel(FNFT_UINT D, fnft__akns_discretization_t discretization);
 FNFT_INT fnft__akns_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q,
@@ -260,6 +278,16 @@ FNFT_INT fnft_amd_nsev_contspec_device(fnft_amd_plan_t *plan, const void *d_q, v
                                        fnft_nsev_cstype_t contspec_type,
                                        FNFT_INT normalization_flag, void *stream);
 FNFT_INT fnft_amd_plan_finish(fnft_amd_plan_t *plan, void *stream);
+
+/* nsev_compute_contspec (src/fnft_nsev.c:744-891) alone: continuous spectrum from a transfer matrix the caller
+ * holds in DEVICE memory -- per signal [r11|r12|r21|r22], each D*deg0+1 complex128, highest power first (the
+ * layout of fnft__poly_fmult2x2 / fnft_amd_plan_get_transfer_matrix_device), true matrix = stored * 2^W --
+ * on the plan's M-point grid (chirp-z of entries 11 and 21, phase factors, rho / a / b).  T is the interval of
+ * the plan's D samples.  Status (FNFT_EC_DIV_BY_ZERO where a(xi) = 0 exactly, src/fnft_nsev.c:850-853) through
+ * fnft_amd_plan_finish.  Used by the root of the sample-axis split (fnft_amd/sharding.py). */
+FNFT_INT fnft_amd_nsev_contspec_from_tm_device(fnft_amd_plan_t *plan, const void *d_tm, FNFT_INT W, void *d_contspec,
+                                               const FNFT_REAL *T, const FNFT_REAL *XI,
+                                               fnft_nsev_cstype_t contspec_type, void *stream);
 
 /* Time (ms) the product tree / the chirp-z+epilogue stage took in the last finished call,
  * measured with HIP events on the stream the kernels ran on.  which: 0 = coefficients + tree,

@@ -301,6 +301,14 @@ class Oracle:
         C.CDLL(None).free(out)
         return 0, arr, ds.value, (fl[0], fl[1])
 
+    def misc_resample(self, q, eps_t, delta):
+        """fnft__misc_resample (fnft__misc.c:326-407) -> (rc, q_new)."""
+        q = _c128(q)
+        out = np.zeros(q.size, np.complex128)
+        self.lib.orc_misc_resample.argtypes = [C.c_size_t, C.c_double, C.c_void_p, C.c_double, C.c_void_p]
+        rc = self.lib.orc_misc_resample(q.size, float(eps_t), _ptr(q), float(delta), _ptr(out))
+        return int(rc), out
+
     def scatter_bound_states(self, q_pre, T, lam, ups, skip_b=False):
         q_pre = _c128(q_pre)
         lam = _c128(lam)

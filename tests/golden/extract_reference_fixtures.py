@@ -13,6 +13,9 @@ Sources (relative to /root/reference):
   test/fnft__akns_fscatter/*.c                                           (per-scheme transfer matrices)
   src/private/fnft__nsev_testcases.c:142-287,463-567                     (analytic spectra)
   test/fnft_nsev/*.c                                                     (per-scheme error bounds)
+  test/fnft__misc/fnft__misc_resample_test.c                             (band-limited resampler)
+  test/fnft__poly/fnft__poly_roots_fasteigen_test.c                      (root finder, cubic)
+  test/fnft__nse_scatter/fnft__nse_scatter_bound_states_test_bo.c        (slow scatterer BO: a, a', b)
 """
 import json
 import math
@@ -312,6 +315,40 @@ def main():
                    "discretization": mdisc.group(1) if mdisc else "2SPLIT8B",
                    "stages": walk_stages(s2, arr_pat=r"eb\w*|error_bounds\w*", harness="kdvv_testcases_test_fnft")})
     out["kdvv_error_bounds"] = kb
+
+    # ---- pieces the discrete spectrum and the 4SPLIT4 front end rest on ----------------------------
+    # test/fnft__misc/fnft__misc_resample_test.c:28-66: band-limited shift of a chirped sech
+    src = strip_comments(read("test/fnft__misc/fnft__misc_resample_test.c"))
+    mq = re.search(r"q\[i\]\s*=\s*([0-9.]+)\s*\*\s*misc_sech\(t\[i\]\)\s*\*\s*CEXP\(I\s*\*\s*([0-9.]+)\s*\*\s*t\[i\]\)", src)
+    out["misc_resample"] = {
+        "D": int(re.search(r"\bD\s*=\s*(\d+)", src).group(1)),
+        "T0": -float(re.search(r"t\[i\]\s*=\s*-([0-9.]+)\s*\+", src).group(1)),
+        "span": float(re.search(r"eps_t\s*=\s*([0-9.]+)\s*/\s*\(D-1\)", src).group(1)),
+        "signal": "q[i] = amp*sech(t_i)*exp(1j*freq*t_i), exact shifted signal: the same formula at t_i + delta",
+        "amp": float(mq.group(1)), "freq": float(mq.group(2)),
+        "deltas": [float(x) for x in re.search(r"delta\[4\]\s*=\s*\{([^}]*)\}", src).group(1).split(",")],
+        "tol_rel_l1": float(re.search(r"err\s*>\s*([0-9.eE+-]+)", src).group(1)),
+    }
+    # test/fnft__poly/fnft__poly_roots_fasteigen_test.c:27-44: cubic, Hausdorff distance <= 100 eps
+    src = strip_comments(read("test/fnft__poly/fnft__poly_roots_fasteigen_test.c"))
+    out["poly_roots_fasteigen"] = {
+        "deg": 3,
+        "p": [c2l(z) for z in array_init(src, "p")],
+        "roots_exact": [c2l(z) for z in array_init(src, "roots_exact")],
+        "tol_hausdorff": 100 * 2.220446049250313e-16,
+    }
+    # test/fnft__nse_scatter/fnft__nse_scatter_bound_states_test_bo.c:30-131: a, a', b of q = 3 sech(t) at 3 points
+    # (the file computes its three errors against 100 eps but returns SUCCESS whatever they are, :133-140)
+    src = strip_comments(read("test/fnft__nse_scatter/fnft__nse_scatter_bound_states_test_bo.c"))
+    out["nse_scatter_bound_states_bo"] = {
+        "D": 256, "T": [-16.0, 16.0], "signal": "q[i] = 3*sech(T0 + i*eps_t)",
+        "bound_states": [c2l(z) for z in array_init(src, "bound_states")],
+        "a_vals": [c2l(z) for z in array_init(src, "a_vals_exact")],
+        "aprime_vals": [c2l(z) for z in array_init(src, "aprime_vals_exact")],
+        "b_vals": [c2l(z) for z in array_init(src, "b_vals_exact")],
+        "tol_rel_l1_stated": 100 * 2.220446049250313e-16,
+        "note": "the reference test cannot fail on these bounds (it returns SUCCESS unconditionally)",
+    }
 
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_fixtures.json")
     with open(dst, "w") as f:

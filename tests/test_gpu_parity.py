@@ -51,6 +51,24 @@ def test_poly_fmult2x2_golden(capi, fixtures, key, normalize):
     assert S.rel_err(res.ravel(), exact) <= fx["tol_rel_l1"]
 
 
+def test_device_fft_known_answer(capi, fixtures):
+    """test/fnft__fft_wrapper/fnft__fft_wrapper_test.c:31-32: the length-4 known answer of the reference's FFT
+    back end, on the device transforms.  There is no FFT entry point in either library (the reference's wrapper
+    is header-only); the chirp z-transform with A = 1, W = exp(-2 pi i/4), M = 4 IS the DFT of the reversed
+    coefficient vector, and on the GPU it runs three workgroup FFT passes per direction (columns and rows of an
+    8192-point transform, forward and inverse), so a wrong butterfly, twiddle or exchange shows up here at 100 eps."""
+    x = S.l2c(fixtures["fft_wrapper"]["in_exact"])
+    X = S.l2c(fixtures["fft_wrapper"]["out_exact"])
+    # result[m] = sum_n p[deg-n] (A W^-m)^-n... with A = 1: sum_n p[deg - n] W^{m n}: p = reversed x
+    rc, out = capi.poly_chirpz(x[::-1].copy(), 1.0 + 0j, np.exp(-2j * np.pi / 4), 4)
+    assert rc == 0, capi.last_error()
+    assert S.rel_err(out, X) <= 100 * 2.220446049250313e-16
+    # inverse direction (sign +1, no 1/N), :53-60 of the same file: W = exp(+2 pi i/4) maps out_exact back to 4*in
+    rc, back = capi.poly_chirpz(X[::-1].copy(), 1.0 + 0j, np.exp(2j * np.pi / 4), 4)
+    assert rc == 0
+    assert S.rel_err(back, 4 * x) <= 100 * 2.220446049250313e-16
+
+
 def test_poly_chirpz_golden(capi, fixtures):
     fx = fixtures["chirpz"]
     p = S.l2c(fx["p"])
@@ -463,6 +481,12 @@ def test_kdvv_cfg5_full_size(capi, oracle, fixtures):
     assert (M - 1) % 15 == 0
     assert S.rel_err(cs[idx], exact) < 1e-7
     plan.close()
+    # the oracle on the same grid (about 30 s of CPU: the degree-3.1e6 tree).  On a coarser sub-grid the two agree
+    # only to 4e-8: the chirp phases W^(n^2/2), n up to 3.1e6, lose accuracy with the larger grid step in either
+    # implementation -- the same floor the analytic bound above allows for.
+    rc2, ref = oracle.fnft_kdvv(u, T, M, XI, "2SPLIT8B")
+    assert rc2 == 0
+    assert S.rel_err(cs, ref) < 5e-10   # measured 7.5e-12 (round 1 bench leg)
 
 
 # ---- discrete spectrum (bound states, norming constants, residues) -------------------------------
@@ -684,3 +708,128 @@ def test_discrete_spectrum_options(capi, oracle, fixtures):
         L.fnft_errwarn_setprintf(old)
     assert rc == 0 and bsk.size == 2
     assert any(b"Warning" in m for m in msgs)
+
+
+# ---- seams under the discrete spectrum / the 4SPLIT4 front end, with the reference's own vectors ---------
+def _hausdorff(x, y):
+    return max(max(min(abs(a - b) for b in y) for a in x), max(min(abs(a - b) for b in x) for a in y))
+
+
+def test_misc_resample_golden(capi, oracle, fixtures):
+    """fnft__misc_resample on the GPU (DFT of length 1256 by Bluestein, phase ramp, inverse DFT) with
+    test/fnft__misc/fnft__misc_resample_test.c:28-66 (rel-L1 <= 3e-7 against the analytically shifted signal)
+    and against the oracle."""
+    f = fixtures["misc_resample"]
+    D = f["D"]
+    eps = f["span"] / (D - 1)
+    t = f["T0"] + np.arange(D) * eps
+    sig = lambda tt: f["amp"] / np.cosh(tt) * np.exp(1j * f["freq"] * tt)   # noqa: E731
+    for delta in f["deltas"]:
+        rc, qn = capi.misc_resample(sig(t), eps, delta)
+        assert rc == 0, capi.last_error()
+        assert S.rel_err(qn, sig(t + delta)) <= f["tol_rel_l1"]
+        rc2, qo = oracle.misc_resample(sig(t), eps, delta)
+        assert rc2 == 0 and S.rel_err(qn, qo) < 1e-12
+    assert capi.misc_resample(sig(t)[:2], eps, 0.1)[0] == 2   # D <= 2: fnft__misc.c:331-332
+
+
+def test_poly_roots_fasteigen_golden(capi, fixtures):
+    """fnft__poly_roots_fasteigen (Ehrlich-Aberth kernels in place of eiscor) with
+    test/fnft__poly/fnft__poly_roots_fasteigen_test.c:27-44 as a SET comparison (Hausdorff distance <= 100 eps),
+    plus polynomials built from known roots: a cluster, a double root (coincident estimates must not freeze)
+    and 600 roots on two circles."""
+    f = fixtures["poly_roots_fasteigen"]
+    rc, r = capi.poly_roots_fasteigen(S.l2c(f["p"]))
+    assert rc == 0, capi.last_error()
+    assert _hausdorff(r, S.l2c(f["roots_exact"])) <= f["tol_hausdorff"]
+    rng = np.random.default_rng(5)
+    known = np.concatenate([0.9 * np.exp(2j * np.pi * rng.random(50)), 1.3 * np.exp(2j * np.pi * rng.random(50))])
+    rc, r = capi.poly_roots_fasteigen(np.poly(known))
+    assert rc == 0 and _hausdorff(r, known) < 5e-6     # conditioning of np.poly coefficients; sweeps stop at the evaluation-noise level
+    # 600 well-conditioned roots, known exactly: (z^300 - a)(z^300 - b), two circles of radius 0.9 and 1.3
+    n = 300
+    known = np.concatenate([0.9 * np.exp(2j * np.pi * (np.arange(n) + 0.3) / n),
+                            1.3 * np.exp(2j * np.pi * (np.arange(n) + 0.1) / n)])
+    a, b = (0.9 * np.exp(2j * np.pi * 0.3 / n)) ** n, (1.3 * np.exp(2j * np.pi * 0.1 / n)) ** n
+    c = np.zeros(2 * n + 1, np.complex128)
+    c[0], c[n], c[2 * n] = 1.0, -(a + b), a * b
+    rc, r = capi.poly_roots_fasteigen(c)
+    assert rc == 0 and _hausdorff(r, known) < 1e-12
+    clustered = np.array([0.5 + 0.5j, 0.5 + 0.5j + 1e-4, 0.5 + 0.5j - 1e-4j, -0.3j, 2.0])
+    rc, r = capi.poly_roots_fasteigen(np.poly(clustered))
+    assert rc == 0 and _hausdorff(r, clustered) < 2e-6   # three roots 1e-4 apart: sensitivity eps/sep^2 times the stopping level
+    double = np.array([0.25 + 0.1j, 0.25 + 0.1j, -1.0, 0.7j])
+    rc, r = capi.poly_roots_fasteigen(np.poly(double))
+    assert rc in (0, -5)                               # a double root converges linearly: accepted or reported
+    assert _hausdorff(r, double) < 1e-6
+
+
+def test_scatter_bound_states_bo_golden(capi, oracle, fixtures):
+    """fnft__nse_scatter_bound_states (BO) on the GPU with
+    test/fnft__nse_scatter/fnft__nse_scatter_bound_states_test_bo.c:30-131 and against the oracle; for the
+    tolerance on b see tests/test_oracle_golden.py::test_scatter_bound_states_bo_golden."""
+    f = fixtures["nse_scatter_bound_states_bo"]
+    D, T = f["D"], f["T"]
+    eps = (T[1] - T[0]) / (D - 1)
+    q = 3.0 / np.cosh(T[0] + np.arange(D) * eps) + 0j
+    lam = S.l2c(f["bound_states"])
+    rc, a, ap, b = capi.nse_scatter_bound_states(q, T, lam)
+    assert rc == 0, capi.last_error()
+    assert np.max(np.abs(a - S.l2c(f["a_vals"]))) < 1e-13
+    assert S.rel_err(ap, S.l2c(f["aprime_vals"])) < 1e-12
+    assert S.rel_err(b, S.l2c(f["b_vals"])) < 5e-3
+    rc2, ao, apo, bo = oracle.scatter_bound_states(q, T, lam, 1)
+    assert rc2 == 0
+    assert np.max(np.abs(a - ao)) < 1e-14 and S.rel_err(ap, apo) < 1e-13 and S.rel_err(b, bo) < 1e-10
+    assert capi.nse_scatter_bound_states(q, T, lam, discretization="CF4_2")[0] == 6   # not covered: says so
+
+
+def test_contspec_from_transfer_matrix_and_div_by_zero(capi, oracle):
+    """nsev_compute_contspec on a caller-supplied transfer matrix (fnft_amd_nsev_contspec_from_tm_device):
+    (i) fed with the plan's own transfer matrix it reproduces the spectrum of the full call; (ii) a transfer
+    matrix whose a-polynomial vanishes gives H11 == 0 at every grid point, the branch src/fnft_nsev.c:850-853
+    -- FNFT_EC_DIV_BY_ZERO, wrapped to -3 like every error of a callee; contspec_type AB has no division and
+    succeeds (:861-876)."""
+    import torch
+    D, M = 1024, 64
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    q = torch.from_numpy(S.sech_focusing(D)).cuda()
+    for disc, deg0 in (("2SPLIT2_MODAL", 1), ("2SPLIT4B", 2)):
+        plan = capi.Plan(D, M, batch=1, discretization=disc)
+        out = torch.zeros(3 * M, dtype=torch.complex128, device="cuda")
+        assert plan.contspec_device(q.data_ptr(), out.data_ptr(), T, XI) == 0 and plan.finish() == 0
+        tm = torch.zeros(4 * (D * deg0 + 1), dtype=torch.complex128, device="cuda")
+        rc, deg, W = plan.transfer_matrix_device(tm.data_ptr())
+        assert rc == 0 and deg == D * deg0
+        out2 = torch.zeros(3 * M, dtype=torch.complex128, device="cuda")
+        assert plan.contspec_from_tm_device(tm.data_ptr(), W, out2.data_ptr(), T, XI) == 0 and plan.finish() == 0
+        assert S.rel_err(out2.cpu().numpy(), out.cpu().numpy()) < 1e-13
+        rc_o, ref = oracle.fnft_nsev(S.sech_focusing(D), T, M, XI, kappa=1, disc=disc, cstype="BOTH")
+        assert rc_o == 0 and S.rel_err(out2.cpu().numpy(), ref) < 1e-12
+        # a(z) == 0: entry 11 zeroed
+        tm0 = tm.clone()
+        tm0[: D * deg0 + 1] = 0
+        assert plan.contspec_from_tm_device(tm0.data_ptr(), W, out2.data_ptr(), T, XI, "BOTH") == 0
+        assert plan.finish() == -3          # -FNFT_EC_DIV_BY_ZERO
+        assert plan.contspec_from_tm_device(tm0.data_ptr(), W, out2.data_ptr(), T, XI, "REFLECTION_COEFFICIENT") == 0
+        assert plan.finish() == -3
+        assert plan.contspec_from_tm_device(tm0.data_ptr(), W, out2.data_ptr(), T, XI, "AB") == 0
+        assert plan.finish() == 0           # no division in a, b
+        plan.close()
+
+
+def test_discrete_spectrum_cfg4_normconsts_vs_oracle(capi, oracle, fixtures):
+    """BASELINE.json configs[3] at full size: the norming constants and residues the GPU returns at D = 2^20 against
+    the ORACLE's slow scatterer (BO, all 2^20 samples, sequential) evaluated at the GPU's own bound states:
+    b = phi/psi, residue = b/a'.  (The oracle's root finder is not run at this size; the bound states themselves are
+    pinned by the exact eigenvalues in test_discrete_spectrum_cfg4_full_size.)"""
+    fx = fixtures["nsev_sech_focusing"]
+    D = 1 << 20
+    q = S.sech_focusing(D)
+    rc, bs, nc, res = capi.fnft_nsev_ds(q, fx["T"], discretization="2SPLIT4B")
+    assert rc == 0 and bs.size == 3, (rc, bs)
+    rc2, a, ap, b = oracle.scatter_bound_states(q, fx["T"], bs, 1)
+    assert rc2 == 0
+    assert np.max(np.abs(a)) < 1e-8                       # Newton converged onto zeros of the discrete a
+    assert S.rel_err(nc, b) < 1e-9
+    assert S.rel_err(res, b / ap) < 1e-9

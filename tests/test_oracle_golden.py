@@ -254,3 +254,48 @@ def test_fnft_nsev_discrete_spectrum_bounds(oracle, fixtures, b):
         for e, bound in zip(errs, st["bounds_ds"]):
             if np.isfinite(bound):
                 assert e <= bound, (st, errs, b["file"])
+
+
+# ---- pieces under the discrete spectrum and the 4SPLIT4 front end, with the reference's own vectors ------
+def _hausdorff(x, y):
+    return max(max(min(abs(a - b) for b in y) for a in x), max(min(abs(a - b) for b in x) for a in y))
+
+
+def test_misc_resample_golden(oracle, fixtures):
+    """test/fnft__misc/fnft__misc_resample_test.c:28-66: shift of a chirped sech by four deltas, rel-L1 <= 3e-7."""
+    f = fixtures["misc_resample"]
+    D = f["D"]
+    eps = f["span"] / (D - 1)
+    t = f["T0"] + np.arange(D) * eps
+    sig = lambda tt: f["amp"] / np.cosh(tt) * np.exp(1j * f["freq"] * tt)   # noqa: E731
+    for delta in f["deltas"]:
+        rc, qn = oracle.misc_resample(sig(t), eps, delta)
+        assert rc == 0
+        assert S.rel_err(qn, sig(t + delta)) <= f["tol_rel_l1"]
+
+
+def test_poly_roots_golden(fixtures):
+    """test/fnft__poly/fnft__poly_roots_fasteigen_test.c:27-44 (Hausdorff distance <= 100 eps) on the checker's
+    root finder (numpy.roots below degree 2500, oracle/oracle.py: poly_roots)."""
+    from oracle.oracle import poly_roots
+    f = fixtures["poly_roots_fasteigen"]
+    r = poly_roots(S.l2c(f["p"]))
+    assert _hausdorff(r, S.l2c(f["roots_exact"])) <= f["tol_hausdorff"]
+
+
+def test_scatter_bound_states_bo_golden(oracle, fixtures):
+    """test/fnft__nse_scatter/fnft__nse_scatter_bound_states_test_bo.c:30-131.  a' agrees to round-off; a is a
+    near-zero (|a| ~ 2e-5 at points that are eigenvalues of the continuous problem only), so it is compared
+    with an absolute tolerance; b = phi/psi depends on the matching point at O(|a|) when a != 0, and the
+    file's values come from a MATLAB rule (norm-balanced split) that differs from the C code's minimum-error
+    rule (fnft__nse_scatter_bound_states.c:481-654) -- the reference's own test returns SUCCESS whatever the
+    errors are (:133-140), so b is pinned only to 5e-3 here ("parity unpinned" beyond that)."""
+    f = fixtures["nse_scatter_bound_states_bo"]
+    D, T = f["D"], f["T"]
+    eps = (T[1] - T[0]) / (D - 1)
+    q = 3.0 / np.cosh(T[0] + np.arange(D) * eps) + 0j
+    rc, a, ap, b = oracle.scatter_bound_states(q, T, S.l2c(f["bound_states"]), 1)
+    assert rc == 0
+    assert np.max(np.abs(a - S.l2c(f["a_vals"]))) < 1e-13
+    assert S.rel_err(ap, S.l2c(f["aprime_vals"])) < 1e-12
+    assert S.rel_err(b, S.l2c(f["b_vals"])) < 5e-3
