@@ -78,7 +78,8 @@ EXPORTED = [
     "fnft_amd_plan_launch_count", "fnft_amd_plan_launch_ms", "fnft_amd_plan_get_transfer_matrix",
     "fnft_amd_plan_get_transfer_matrix_device", "fnft_amd_plan_device", "fnft_amd_current_device",
     "fnft_amd_nsev_contspec_from_tm_device", "fnft__misc_resample", "fnft__poly_roots_fasteigen",
-    "fnft__nse_scatter_bound_states",
+    "fnft__nse_scatter_bound_states", "fnft__poly_fmult_numel", "fnft__poly_fmult", "fnft__poly_fmult_two_polys_len",
+    "fnft__poly_fmult_two_polys", "fnft__poly_fmult_two_polys2x2",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -177,6 +178,16 @@ def load(path=None):
     L.fnft__poly_roots_fasteigen.argtypes = [sz, vp, vp]
     L.fnft__nse_scatter_bound_states.restype = i32
     L.fnft__nse_scatter_bound_states.argtypes = [sz, vp, vp, vp, sz, vp, vp, vp, vp, C.c_int, sz]
+    L.fnft__poly_fmult_numel.restype = sz
+    L.fnft__poly_fmult_numel.argtypes = [sz, sz]
+    L.fnft__poly_fmult.restype = i32
+    L.fnft__poly_fmult.argtypes = [C.POINTER(sz), sz, vp, C.POINTER(i32)]
+    L.fnft__poly_fmult_two_polys_len.restype = i32
+    L.fnft__poly_fmult_two_polys_len.argtypes = [sz]
+    L.fnft__poly_fmult_two_polys.restype = i32
+    L.fnft__poly_fmult_two_polys.argtypes = [sz, vp, vp, vp, vp, vp, vp, vp, vp, sz]
+    L.fnft__poly_fmult_two_polys2x2.restype = i32
+    L.fnft__poly_fmult_two_polys2x2.argtypes = [sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, sz]
     L.fnft_amd_plan_device.restype = C.c_int
     L.fnft_amd_plan_device.argtypes = [vp]
     L.fnft_amd_current_device.restype = C.c_int
@@ -285,6 +296,46 @@ def fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="SUBSAMPLE_AND_REFINE", 
     res = nc[k:2 * k] if d == 2 else (nc[:k] if d == 1 else None)
     out = (int(rc), bs[:k].copy(), None if ncs is None else ncs.copy(), None if res is None else res.copy())
     return out + ((cs,) if M > 0 else ())
+
+
+def poly_fmult(deg, n, p, normalize=True):
+    """fnft__poly_fmult: n scalar polynomials of degree deg (p[n*(deg+1)]) -> (rc, deg_out, product[deg_out+1], W)."""
+    L = load()
+    buf = np.zeros(max(int(L.fnft__poly_fmult_numel(deg, n)), 1), np.complex128)
+    p = _c128(p).ravel()
+    buf[: p.size] = p
+    d = C.c_size_t(deg)
+    W = C.c_int32(0)
+    rc = L.fnft__poly_fmult(C.byref(d), n, _ptr(buf), C.byref(W) if normalize else None)
+    return int(rc), int(d.value), buf[: d.value + 1].copy(), int(W.value)
+
+
+def poly_fmult_two_polys(p1, p2, result=None, mode=0, bufs=None):
+    """fnft__poly_fmult_two_polys: (rc, result[len]); p1 / p2 None = the previous call's factor (kept in bufs);
+    result / bufs are the caller's persistent buffers (allocated on first use)."""
+    L = load()
+    deg = (len(p1) if p1 is not None else len(p2)) - 1
+    ln = int(L.fnft__poly_fmult_two_polys_len(deg))
+    if bufs is None:
+        bufs = [np.zeros(ln, np.complex128) for _ in range(3)]
+    if result is None:
+        result = np.zeros(ln, np.complex128)
+    a = None if p1 is None else _c128(p1)
+    b = None if p2 is None else _c128(p2)
+    rc = L.fnft__poly_fmult_two_polys(deg, None if a is None else _ptr(a), None if b is None else _ptr(b), _ptr(result),
+                                      None, None, _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]), mode)
+    return int(rc), result, bufs
+
+
+def poly_fmult_two_polys2x2(p1, p2):
+    """fnft__poly_fmult_two_polys2x2: p1, p2 [4, deg+1] -> (rc, result[4, 2*deg+1])."""
+    L = load()
+    p1, p2 = _c128(p1), _c128(p2)
+    deg = p1.shape[1] - 1
+    res = np.zeros((4, 2 * deg + 1), np.complex128)
+    rc = L.fnft__poly_fmult_two_polys2x2(deg, _ptr(p1), deg + 1, _ptr(p2), deg + 1, _ptr(res), 2 * deg + 1, None, None,
+                                         None, None, None, 0)
+    return int(rc), res
 
 
 def misc_resample(q, eps_t, delta):

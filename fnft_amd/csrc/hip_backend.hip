@@ -396,6 +396,122 @@ FNFT_INT fnft__poly_fmult2x2(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *cons
     return api_poly_fmult2x2(be, d, n, p, result, W_ptr);
 }
 
+// ---- scalar products and single pair products (src/private/fnft__poly_fmult.c:35-38,45-121,152-328) ----------
+// They ride on the 2x2 tree: a scalar polynomial p is the matrix diag(p, p), whose products have the scalar
+// product in entry 11.
+FNFT_UINT fnft__poly_fmult_numel(const FNFT_UINT deg, const FNFT_UINT n)
+{
+    return (deg + 1) * (n == 0 ? 0 : nft_nextpow2(n));
+}
+
+FNFT_INT fnft__poly_fmult(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *const p, FNFT_INT *const W_ptr)
+{
+    if (!d || !p || n == 0 || *d == 0) return FNFT_EC_INVALID_ARGUMENT;
+    const int dev = current_device();
+    if (dev < 0) return FNFT_EC_OTHER;
+    const size_t deg = *d, w = deg + 1;
+    std::vector<std::complex<double>> m(fnft__poly_fmult2x2_numel(deg, n)), r(m.size());
+    for (size_t i = 0; i < n * w; i++) {
+        m[i] = p[i];                  // entry 11
+        m[3 * n * w + i] = p[i];      // entry 22
+    }
+    HipBackend be;
+    size_t dd = deg;
+    const int rc = api_poly_fmult2x2(be, &dd, n, m.data(), r.data(), W_ptr);
+    if (rc != FNFT_SUCCESS) return rc;
+    for (size_t i = 0; i <= dd; i++) p[i] = r[i];
+    *d = dd;
+    return FNFT_SUCCESS;
+}
+
+// fft_wrapper_next_fft_length(2*(deg+1)-1), include/private/fnft__fft_wrapper.h:43-48 (kiss_fft_next_fast_size):
+// the length callers of the reference size buf0..buf2 with
+FNFT_INT fnft__poly_fmult_two_polys_len(const FNFT_UINT deg)
+{
+    size_t n = 2 * (deg + 1) - 1;
+    for (;; n++) {
+        size_t m = n;
+        while (m % 2 == 0) m /= 2;
+        while (m % 3 == 0) m /= 3;
+        while (m % 5 == 0) m /= 5;
+        if (m <= 1) return (FNFT_INT)n;
+    }
+}
+
+static int two_polys_product(size_t deg, const std::complex<double> *p1, const std::complex<double> *p2,
+                             std::complex<double> *out /* 2*deg+1 */)
+{
+    const size_t w = deg + 1;
+    std::vector<std::complex<double>> m(fnft__poly_fmult2x2_numel(deg, 2)), r(m.size());
+    for (size_t i = 0; i < w; i++) {
+        m[i] = p1[i];           m[w + i] = p2[i];                  // entry 11 of both factors
+        m[6 * w + i] = p1[i];   m[7 * w + i] = p2[i];              // entry 22
+    }
+    HipBackend be;
+    size_t dd = deg;
+    const int rc = api_poly_fmult2x2(be, &dd, 2, m.data(), r.data(), nullptr);
+    if (rc != FNFT_SUCCESS) return rc;
+    for (size_t i = 0; i <= 2 * deg; i++) out[i] = r[i];
+    return FNFT_SUCCESS;
+}
+
+// src/private/fnft__poly_fmult.c:50-121.  plan_fwd / plan_inv are the reference's KissFFT / FFTW handles: the GPU
+// does its own transforms and ignores them (pass whatever the caller has, or NULL).  The reference keeps the
+// SPECTRA of p1 / p2 in buf1 / buf2 between calls (a NULL factor means "the one of the previous call") and, in
+// modes 2 / 3, a partial sum of spectra in `result`; here the same buffers carry the COEFFICIENTS instead --
+// what a sequence of calls returns in the coefficient domain (modes 0, 1, 3) is the same.
+FNFT_INT fnft__poly_fmult_two_polys(const FNFT_UINT deg, FNFT_COMPLEX const *const p1, FNFT_COMPLEX const *const p2,
+                                    FNFT_COMPLEX *const result, void *plan_fwd, void *plan_inv, FNFT_COMPLEX *const buf0,
+                                    FNFT_COMPLEX *const buf1, FNFT_COMPLEX *const buf2, const FNFT_UINT mode)
+{
+    (void)plan_fwd; (void)plan_inv; (void)buf0;
+    if (!result || !buf1 || !buf2 || mode > 3) return FNFT_EC_INVALID_ARGUMENT;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    const size_t w = deg + 1, wr = 2 * deg + 1;
+    if (p1) for (size_t i = 0; i < w; i++) buf1[i] = p1[i];
+    if (p2) for (size_t i = 0; i < w; i++) buf2[i] = p2[i];
+    std::vector<std::complex<double>> prod(wr);
+    if (deg == 0) prod[0] = buf1[0] * buf2[0];
+    else {
+        const int rc = two_polys_product(deg, buf1, buf2, prod.data());
+        if (rc != FNFT_SUCCESS) return rc;
+    }
+    switch (mode) {
+    case 0: for (size_t i = 0; i < wr; i++) result[i] = prod[i]; break;
+    case 1: for (size_t i = 0; i < wr; i++) result[i] += prod[i]; break;
+    case 2: for (size_t i = 0; i < wr; i++) result[i] = prod[i]; break;    // partial sum kept for a mode-3 call
+    default: for (size_t i = 0; i < wr; i++) result[i] += prod[i]; break;  // mode 3: partial sum + this product
+    }
+    return FNFT_SUCCESS;
+}
+
+// src/private/fnft__poly_fmult.c:239-328: one 2x2 product, entries at the given strides; plans, buffers and
+// mode_offset (where the reference parks spectra) are not needed and ignored
+FNFT_INT fnft__poly_fmult_two_polys2x2(const FNFT_UINT deg, FNFT_COMPLEX const *const p1_11, const FNFT_UINT p1_stride,
+                                       FNFT_COMPLEX const *const p2_11, const FNFT_UINT p2_stride,
+                                       FNFT_COMPLEX *const result_11, const FNFT_UINT result_stride, void *plan_fwd,
+                                       void *plan_inv, FNFT_COMPLEX *const buf0, FNFT_COMPLEX *const buf1,
+                                       FNFT_COMPLEX *const buf2, const FNFT_UINT mode_offset)
+{
+    (void)plan_fwd; (void)plan_inv; (void)buf0; (void)buf1; (void)buf2; (void)mode_offset;
+    if (!p1_11 || !p2_11 || !result_11 || deg == 0) return FNFT_EC_INVALID_ARGUMENT;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    const size_t w = deg + 1, wr = 2 * deg + 1;
+    std::vector<std::complex<double>> m(fnft__poly_fmult2x2_numel(deg, 2)), r(m.size());
+    for (int e = 0; e < 4; e++)
+        for (size_t i = 0; i < w; i++) {
+            m[(size_t)e * 2 * w + i] = p1_11[(size_t)e * p1_stride + i];
+            m[(size_t)e * 2 * w + w + i] = p2_11[(size_t)e * p2_stride + i];
+        }
+    HipBackend be;
+    size_t dd = deg;
+    const int rc = api_poly_fmult2x2(be, &dd, 2, m.data(), r.data(), nullptr);
+    if (rc != FNFT_SUCCESS) return rc;
+    for (int e = 0; e < 4; e++)
+        for (size_t i = 0; i < wr; i++) result_11[(size_t)e * result_stride + i] = r[(size_t)e * wr + i];
+    return FNFT_SUCCESS;
+}
+
 FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const double *A,
                               const double *W, const FNFT_UINT M, FNFT_COMPLEX *const result)
 {

@@ -188,6 +188,29 @@ FNFT_UINT fnft__poly_fmult2x2_numel(const FNFT_UINT deg, const FNFT_UINT n);
 FNFT_INT fnft__poly_fmult2x2(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *const p,
                              FNFT_COMPLEX *const result, FNFT_INT *const W_ptr);
 
+/* include/private/fnft__poly_fmult.h:162,183-184 (src/private/fnft__poly_fmult.c:35-38,152-237): product of n scalar
+ * polynomials of degree *d, in place (p holds n*(deg+1) coefficients on entry, the (*d)+1 coefficients of the
+ * product on return; sized by fnft__poly_fmult_numel); *W_ptr as in fnft__poly_fmult2x2. */
+FNFT_UINT fnft__poly_fmult_numel(const FNFT_UINT deg, const FNFT_UINT n);
+FNFT_INT fnft__poly_fmult(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *const p, FNFT_INT *const W_ptr);
+
+/* include/private/fnft__poly_fmult.h:39,82-92,136-148 (src/private/fnft__poly_fmult.c:45-121,239-328): one product of
+ * two polynomials / of two 2x2 polynomial matrices of degree deg -- the calls fnft__nse_finvscatter.c:128,155 makes.
+ * plan_fwd / plan_inv (the reference's FFT-wrapper handles) and the scratch buffers are accepted for call
+ * compatibility and not used by the GPU transforms, except that buf1 / buf2 carry the factors from one call of
+ * fnft__poly_fmult_two_polys to the next (a NULL factor = the previous call's) and `result` the partial sum between a
+ * mode-2 and a mode-3 call -- as coefficients, where the reference keeps spectra.  fnft__poly_fmult_two_polys_len is the
+ * reference's buffer length (kiss_fft_next_fast_size(2*deg+1)). */
+FNFT_INT fnft__poly_fmult_two_polys_len(const FNFT_UINT deg);
+FNFT_INT fnft__poly_fmult_two_polys(const FNFT_UINT deg, FNFT_COMPLEX const *const p1, FNFT_COMPLEX const *const p2,
+                                    FNFT_COMPLEX *const result, void *plan_fwd, void *plan_inv, FNFT_COMPLEX *const buf0,
+                                    FNFT_COMPLEX *const buf1, FNFT_COMPLEX *const buf2, const FNFT_UINT mode);
+FNFT_INT fnft__poly_fmult_two_polys2x2(const FNFT_UINT deg, FNFT_COMPLEX const *const p1_11, const FNFT_UINT p1_stride,
+                                       FNFT_COMPLEX const *const p2_11, const FNFT_UINT p2_stride,
+                                       FNFT_COMPLEX *const result_11, const FNFT_UINT result_stride, void *plan_fwd,
+                                       void *plan_inv, FNFT_COMPLEX *const buf0, FNFT_COMPLEX *const buf1,
+                                       FNFT_COMPLEX *const buf2, const FNFT_UINT mode_offset);
+
 /* include/private/fnft__poly_chirpz.h:61 (src/private/fnft__poly_chirpz.c:33-105).
  * A and W are passed as pointers to {re, im} here (complex-by-value does not cross every FFI);
  * fnft__poly_chirpz below is the by-value form with the reference's exact signature. */

@@ -143,6 +143,19 @@ def main():
             "tol_rel_l1": 100 * 2.220446049250313e-16,
         }
 
+    # scalar tree, test/fnft__poly/fnft__poly_fmult_test_n_is_power_of_2.c:26-77 and ..._no_power_of_2.c:26-88
+    for key, rel, n in (
+        ("fmult_pow2", "test/fnft__poly/fnft__poly_fmult_test_n_is_power_of_2.c", 8),
+        ("fmult_nopow2", "test/fnft__poly/fnft__poly_fmult_test_n_is_no_power_of_2.c", 11),
+    ):
+        src = strip_comments(read(rel))
+        out[key] = {
+            "deg": 2, "n": n,
+            "input_rule": "p[i] = sqrt(i+1)*(cos(i) + 1j*sin(-2*i)), i < (deg+1)*n",
+            "result_exact": [c2l(z) for z in array_init(src, "result_exact")],
+            "tol_rel_l1": 100 * 2.220446049250313e-16,
+        }
+
     # ---- chirp z ------------------------------------------------------------------------
     src = strip_comments(read("test/fnft__poly/fnft__poly_chirpz_test.c"))
     out["chirpz"] = {

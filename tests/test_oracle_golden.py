@@ -299,3 +299,17 @@ def test_scatter_bound_states_bo_golden(oracle, fixtures):
     assert np.max(np.abs(a - S.l2c(f["a_vals"]))) < 1e-13
     assert S.rel_err(ap, S.l2c(f["aprime_vals"])) < 1e-12
     assert S.rel_err(b, S.l2c(f["b_vals"])) < 5e-3
+
+
+@pytest.mark.parametrize("key", ["fmult_pow2", "fmult_nopow2"])
+def test_poly_fmult_scalar_vectors(fixtures, key):
+    """test/fnft__poly/fnft__poly_fmult_test_n_is_power_of_2.c:26-77 / ..._no_power_of_2.c:26-88: the MATLAB vectors
+    against direct convolution of the input rule (the scalar tree of the GPU library is tested with them, -m gpu)."""
+    f = fixtures[key]
+    deg, n = f["deg"], f["n"]
+    i = np.arange((deg + 1) * n, dtype=np.float64)
+    p = np.sqrt(i + 1.0) * (np.cos(i) + 1j * np.sin(-2.0 * i))
+    r = p[: deg + 1]
+    for j in range(1, n):
+        r = np.convolve(r, p[j * (deg + 1):(j + 1) * (deg + 1)])
+    assert S.rel_err(r, S.l2c(f["result_exact"])) <= f["tol_rel_l1"]
