@@ -79,7 +79,7 @@ EXPORTED = [
     "fnft_amd_plan_get_transfer_matrix_device", "fnft_amd_plan_device", "fnft_amd_current_device",
     "fnft_amd_nsev_contspec_from_tm_device", "fnft__misc_resample", "fnft__poly_roots_fasteigen",
     "fnft__nse_scatter_bound_states", "fnft__poly_fmult_numel", "fnft__poly_fmult", "fnft__poly_fmult_two_polys_len",
-    "fnft__poly_fmult_two_polys", "fnft__poly_fmult_two_polys2x2",
+    "fnft__poly_fmult_two_polys", "fnft__poly_fmult_two_polys2x2", "fnft__nse_finvscatter",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -188,6 +188,8 @@ def load(path=None):
     L.fnft__poly_fmult_two_polys.argtypes = [sz, vp, vp, vp, vp, vp, vp, vp, vp, sz]
     L.fnft__poly_fmult_two_polys2x2.restype = i32
     L.fnft__poly_fmult_two_polys2x2.argtypes = [sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, sz]
+    L.fnft__nse_finvscatter.restype = i32
+    L.fnft__nse_finvscatter.argtypes = [sz, vp, vp, dbl, i32, C.c_int]
     L.fnft_amd_plan_device.restype = C.c_int
     L.fnft_amd_plan_device.argtypes = [vp]
     L.fnft_amd_current_device.restype = C.c_int
@@ -336,6 +338,17 @@ def poly_fmult_two_polys2x2(p1, p2):
     rc = L.fnft__poly_fmult_two_polys2x2(deg, _ptr(p1), deg + 1, _ptr(p2), deg + 1, _ptr(res), 2 * deg + 1, None, None,
                                          None, None, None, 0)
     return int(rc), res
+
+
+def nse_finvscatter(tm, eps_t, kappa, discretization):
+    """fnft__nse_finvscatter: tm [4, deg+1] -> (rc, q[deg])."""
+    L = load()
+    tm = _c128(tm)
+    deg = tm.shape[1] - 1
+    q = np.zeros(max(deg, 1), np.complex128)
+    d = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    rc = L.fnft__nse_finvscatter(deg, _ptr(tm), _ptr(q), float(eps_t), int(kappa), d)
+    return int(rc), q[:deg]
 
 
 def misc_resample(q, eps_t, delta):

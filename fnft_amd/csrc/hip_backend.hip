@@ -6,6 +6,7 @@
 #include <tuple>
 
 #include "hip_be.h"
+#include "nft_inverse.h"
 #include "../../include/fnft_amd.h"
 
 thread_local std::string g_last_error;
@@ -510,6 +511,38 @@ FNFT_INT fnft__poly_fmult_two_polys2x2(const FNFT_UINT deg, FNFT_COMPLEX const *
     for (int e = 0; e < 4; e++)
         for (size_t i = 0; i < wr; i++) result_11[(size_t)e * result_stride + i] = r[(size_t)e * wr + i];
     return FNFT_SUCCESS;
+}
+
+// include/private/fnft__nse_finvscatter.h (src/private/fnft__nse_finvscatter.c:234-366): samples from a transfer
+// matrix by layer peeling; products of degree >= kInvGpuDeg on the GPU, smaller ones on the host
+struct InvProduct {
+    static constexpr size_t kInvGpuDeg = 512;
+    int operator()(size_t deg, const std::complex<double> *A, size_t As, const std::complex<double> *B, size_t Bs,
+                   std::complex<double> *C, size_t Cs)
+    {
+        if (deg < kInvGpuDeg) { nft_host_product2x2(deg, A, As, B, Bs, C, Cs); return 0; }
+        return fnft__poly_fmult_two_polys2x2(deg, A, As, B, Bs, C, Cs, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    }
+};
+
+FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer_matrix, FNFT_COMPLEX *const q,
+                               const FNFT_REAL eps_t, const FNFT_INT kappa, const fnft_nse_discretization_t discretization)
+{
+    // argument checks in the reference's order, :242-260
+    if (deg == 0 || !transfer_matrix || !q || !(eps_t > 0.0) || (kappa != -1 && kappa != 1)) return FNFT_EC_INVALID_ARGUMENT;
+    const int akns = nft_nse_to_akns((int)discretization);
+    const int ddeg = akns < 0 ? 0 : nft_akns_degree(akns);
+    if (ddeg == 0) return FNFT_EC_INVALID_ARGUMENT;
+    const size_t D = deg / (size_t)ddeg;
+    if (D < 2 || (D & (D - 1)) != 0) return FNFT_EC_OTHER;           // not a power of two, :259-260
+    // the base case exists for the two degree-1 schemes only, :164-211
+    const bool modal = discretization == fnft_nse_discretization_2SPLIT2_MODAL;
+    if (!modal && discretization != fnft_nse_discretization_2SPLIT2A) return FNFT_EC_INVALID_ARGUMENT;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    InvProduct prod;
+    NftLayerPeeling<InvProduct> lp(prod, eps_t, (int)kappa, modal ? 1 : 0);
+    lp.peel(deg, transfer_matrix, deg + 1, nullptr, 0, q);
+    return lp.rc;
 }
 
 FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const double *A,

@@ -109,6 +109,63 @@ def build_oracle(force=False):
     return _LIB
 
 
+def _conv2x2(A, B):
+    """Product of two 2x2 polynomial matrices [4, n] x [4, m] (highest power first) by FFT convolution."""
+    n = A.shape[1] + B.shape[1] - 1
+    L = 1 << int(np.ceil(np.log2(max(n, 1))))
+    FA, FB = np.fft.fft(A, L, axis=1), np.fft.fft(B, L, axis=1)
+    FC = np.stack([FA[0] * FB[0] + FA[1] * FB[2], FA[0] * FB[1] + FA[1] * FB[3],
+                   FA[2] * FB[0] + FA[3] * FB[2], FA[2] * FB[1] + FA[3] * FB[3]])
+    return np.fft.ifft(FC, axis=1)[:, :n]
+
+
+def nse_finvscatter(tm, eps_t, kappa, disc):
+    """Fast inverse scattering by layer peeling, src/private/fnft__nse_finvscatter.c:66-232 (recursion) and
+    :234-366 (driver): tm [4, deg+1] (highest power first, as fnft__nse_fscatter returns it un-normalised) ->
+    (rc, q[deg]).  Only the two degree-1 schemes with a base case (:164-211): 2SPLIT2_MODAL and 2SPLIT2A; the
+    number of samples must be a power of two (:259-260).  Products by FFT convolution as in the reference."""
+    tm = np.asarray(tm, np.complex128)
+    deg = tm.shape[1] - 1
+    if deg < 2 or (deg & (deg - 1)) != 0:
+        return 5, None
+    if disc not in ("2SPLIT2_MODAL", "2SPLIT2A"):
+        return 2, None
+    modal = disc == "2SPLIT2_MODAL"
+    q = np.zeros(deg, np.complex128)
+    state = {"rc": 0}
+
+    def peel(T, want_inverse, q_out):
+        """T [4, d+1] -> inverse up to a power of z ([4, d+1]) if wanted; fills q_out (d samples)."""
+        d = T.shape[1] - 1
+        if state["rc"]:
+            return None
+        if d == 1:                                                       # :158-218
+            Q = -kappa * np.conj(T[2, 1] / T[0, 1])
+            den = 1.0 + kappa * abs(Q) ** 2
+            if den <= 0.0:
+                state["rc"] = 5
+                return None
+            scl = 1.0 / np.sqrt(den)
+            q_out[0] = Q / eps_t if modal else np.arctan(abs(Q)) * np.exp(1j * np.angle(Q)) / eps_t
+            if not want_inverse:
+                return None
+            return np.array([[scl, 0.0], [-scl * Q, 0.0], [0.0, scl * kappa * np.conj(Q)], [0.0, scl]], np.complex128)
+        h = d // 2
+        T2i_low = peel(T[:, h:], True, q_out[h:])                         # step 1, :107-116
+        if state["rc"]:
+            return None
+        T2i = np.zeros((4, d + 1), np.complex128)
+        T2i[:, h:] = T2i_low                                              # degree-d array, upper half zero
+        T1 = _conv2x2(T2i, T)                                             # step 2, :120-127 (2d+1 coefficients)
+        T1i = peel(T1[:, d:d + h + 1], True, q_out[:h])                   # step 3, :131-140
+        if state["rc"] or not want_inverse:
+            return None
+        return _conv2x2(T1i, T2i_low)                                     # step 4, :144-156 (d+1 coefficients)
+
+    peel(tm, False, q)
+    return state["rc"], (q if state["rc"] == 0 else None)
+
+
 def _c128(a):
     return np.ascontiguousarray(a, dtype=np.complex128)
 

@@ -16,6 +16,8 @@ Sources (relative to /root/reference):
   test/fnft__misc/fnft__misc_resample_test.c                             (band-limited resampler)
   test/fnft__poly/fnft__poly_roots_fasteigen_test.c                      (root finder, cubic)
   test/fnft__nse_scatter/fnft__nse_scatter_bound_states_test_bo.c        (slow scatterer BO: a, a', b)
+  test/fnft__poly/fnft__poly_fmult_test_n_is_(no_)power_of_2.c            (scalar product tree)
+  test/fnft__nse_finvscatter/*.c, ..._test.inc                            (inverse scattering round trip, bounds)
 """
 import json
 import math
@@ -361,6 +363,26 @@ def main():
         "b_vals": [c2l(z) for z in array_init(src, "b_vals_exact")],
         "tol_rel_l1_stated": 100 * 2.220446049250313e-16,
         "note": "the reference test cannot fail on these bounds (it returns SUCCESS unconditionally)",
+    }
+
+    # test/fnft__nse_finvscatter/*.c + fnft__nse_finvscatter_test.inc:28-75: fscatter -> finvscatter round trip
+    inc = strip_comments(read("test/fnft__nse_finvscatter/fnft__nse_finvscatter_test.inc"))
+    cases = []
+    d = os.path.join(REF, "test/fnft__nse_finvscatter")
+    for fn in sorted(os.listdir(d)):
+        if not fn.endswith(".c"):
+            continue
+        src = strip_comments(read("test/fnft__nse_finvscatter/" + fn))
+        eps_mults = [float(x) for x in re.findall(r"=\s*([0-9.]+)\s*\*\s*FNFT_EPSILON", src)]
+        cases.append({"file": fn, "kappa": int(re.search(r"kappa\s*=\s*([+-]?\d+)", src).group(1)),
+                      "discretization": re.search(r"fnft_nse_discretization_(\w+)\s*;", src).group(1),
+                      # with FFTW / with KissFFT where the file distinguishes; the looser one is the KissFFT build's
+                      "bound_eps": max(eps_mults)})
+    out["nse_finvscatter"] = {
+        "D": int(re.search(r"\bD\s*=\s*(\d+)", inc).group(1)),
+        "eps_t": float(re.search(r"eps_t\s*=\s*([0-9.]+)", inc).group(1)),
+        "signal": "q[i] = ((i+1)/(D+1)/D)*exp(1j*i/D)",
+        "cases": cases,
     }
 
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_fixtures.json")

@@ -886,3 +886,43 @@ def test_poly_fmult_two_polys_modes(capi):
                     cv(P1[2], P2[0]) + cv(P1[3], P2[2]), cv(P1[2], P2[1]) + cv(P1[3], P2[3])])
     assert S.rel_err(R.ravel(), ref.ravel()) < 1e-14
     assert capi.load().fnft__poly_fmult_two_polys_len(4) == 9 and capi.load().fnft__poly_fmult_two_polys_len(16) == 36
+
+
+# ---- inverse scattering by layer peeling: the other caller of the pair-product kernels -------
+def _finv_cases():
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_fixtures.json")) as f:
+        return [pytest.param(c, id=c["file"].replace("fnft__nse_finvscatter_test_", "").replace(".c", ""))
+                for c in json.load(f)["nse_finvscatter"]["cases"]]
+
+
+@pytest.mark.parametrize("c", _finv_cases())
+def test_nse_finvscatter_round_trip(capi, oracle, fixtures, c):
+    """test/fnft__nse_finvscatter/fnft__nse_finvscatter_test.inc:28-75 on the GPU library: fnft__nse_fscatter (W_ptr =
+    NULL) then fnft__nse_finvscatter returns the D = 16384 samples within the file's bound; and the samples
+    recovered from the ORACLE's transfer matrix agree with the oracle's own inverse."""
+    from oracle.oracle import nse_finvscatter
+    f = fixtures["nse_finvscatter"]
+    D, eps_t = f["D"], f["eps_t"]
+    i = np.arange(D)
+    q_exact = ((i + 1) / (D + 1) / D) * np.exp(1j * i / D)
+    rc, deg, tm, _ = capi.nse_fscatter(q_exact, eps_t, c["kappa"], c["discretization"], normalize=False)
+    assert rc == 0 and deg == D, capi.last_error()
+    rc2, q = capi.nse_finvscatter(tm, eps_t, c["kappa"], c["discretization"])
+    assert rc2 == 0, capi.last_error()
+    assert S.rel_err(q, q_exact) < c["bound_eps"] * 2.220446049250313e-16
+    rc3, _, tm_o, _ = oracle.nse_fscatter(q_exact, eps_t, c["kappa"], c["discretization"], normalize=False)
+    rc4, q_o = nse_finvscatter(tm_o, eps_t, c["kappa"], c["discretization"])
+    rc5, q_g = capi.nse_finvscatter(tm_o, eps_t, c["kappa"], c["discretization"])
+    assert rc3 == 0 and rc4 == 0 and rc5 == 0
+    assert S.rel_err(q_g, q_o) < 2 * c["bound_eps"] * 2.220446049250313e-16
+
+
+def test_nse_finvscatter_arguments(capi):
+    tm = np.ones((4, 9), np.complex128)
+    assert capi.nse_finvscatter(tm, 0.1, 2, "2SPLIT2_MODAL")[0] == 2       # kappa
+    assert capi.nse_finvscatter(tm, -0.1, 1, "2SPLIT2_MODAL")[0] == 2      # eps_t
+    assert capi.nse_finvscatter(np.ones((4, 7), np.complex128), 0.1, 1, "2SPLIT2_MODAL")[0] == 5   # D = 6: no power of two
+    assert capi.nse_finvscatter(tm, 0.1, 1, "2SPLIT4B")[0] in (2, 5)       # no base case for this scheme

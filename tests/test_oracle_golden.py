@@ -313,3 +313,28 @@ def test_poly_fmult_scalar_vectors(fixtures, key):
     for j in range(1, n):
         r = np.convolve(r, p[j * (deg + 1):(j + 1) * (deg + 1)])
     assert S.rel_err(r, S.l2c(f["result_exact"])) <= f["tol_rel_l1"]
+
+
+def _finv_cases():
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_fixtures.json")) as f:
+        return [pytest.param(c, id=c["file"].replace("fnft__nse_finvscatter_test_", "").replace(".c", ""))
+                for c in json.load(f)["nse_finvscatter"]["cases"]]
+
+
+@pytest.mark.parametrize("c", _finv_cases())
+def test_nse_finvscatter_round_trip(oracle, fixtures, c):
+    """test/fnft__nse_finvscatter/fnft__nse_finvscatter_test.inc:28-75 as each of the four files runs it: the
+    D = 16384 samples come back from their own transfer matrix within the file's bound (multiples of eps)."""
+    from oracle.oracle import nse_finvscatter
+    f = fixtures["nse_finvscatter"]
+    D, eps_t = f["D"], f["eps_t"]
+    i = np.arange(D)
+    q_exact = ((i + 1) / (D + 1) / D) * np.exp(1j * i / D)
+    rc, deg, tm, _ = oracle.nse_fscatter(q_exact, eps_t, c["kappa"], c["discretization"], normalize=False)
+    assert rc == 0 and deg == D
+    rc2, q = nse_finvscatter(tm, eps_t, c["kappa"], c["discretization"])
+    assert rc2 == 0
+    assert S.rel_err(q, q_exact) < c["bound_eps"] * 2.220446049250313e-16
