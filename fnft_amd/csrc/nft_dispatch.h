@@ -412,7 +412,8 @@ template <class BE> bool dispatch_pair_fft(BE &be, const TreeLevel &L, int N)
     }
 }
 
-#define FA_FOR_EACH_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
+#define FA_FOR_EACH_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
+#define FA_FOR_EACH_CHIRP_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096)
 
 template <class BE> bool dispatch_col_fwd(BE &be, const BigLevel &G)
 {
@@ -460,7 +461,7 @@ template <class BE> bool dispatch_chirp_col_fwd(BE &be, const ChirpParams &C)
     const int jobs = C.batch * C.npoly + (C.v_mode == 2 ? 0 : 1);   // the filter job is skipped when its spectrum is cached
     switch (C.N1) {
 #define X(n1) case n1: if (C.dft_len > 0) be.template run<KChirpColFwd<n1, true>>(C.N2 / ChirpColCfg<n1>::BC, jobs, C); else be.template run<KChirpColFwd<n1>>(C.N2 / ChirpColCfg<n1>::BC, jobs, C); return true;
-        FA_FOR_EACH_N1(X)
+        FA_FOR_EACH_CHIRP_N1(X)
 #undef X
     default: return false;
     }
@@ -469,7 +470,7 @@ template <class BE> bool dispatch_chirp_col_inv(BE &be, const ChirpParams &C)
 {
     switch (C.N1) {
 #define X(n1) case n1: if (C.dft_len > 0) be.template run<KChirpColInv<n1, true>>(C.N2 / ChirpColCfg<n1>::BC, C.batch, C); else if (C.cstype == 10) be.template run<KChirpColInv<n1, false, true>>(C.N2 / ChirpColCfg<n1>::BC, C.batch, C); else be.template run<KChirpColInv<n1>>(C.N2 / ChirpColCfg<n1>::BC, C.batch, C); return true;
-        FA_FOR_EACH_N1(X)
+        FA_FOR_EACH_CHIRP_N1(X)
 #undef X
     default: return false;
     }

@@ -106,9 +106,9 @@ inline size_t nft_product_len(size_t d)
 }
 
 constexpr int kFineLog2 = 12;           // master twiddle: NMAX = 2^24
-constexpr int kMaxTwTable = 4096;       // per-length tables up to this length
-constexpr size_t kMaxSplitTree = (size_t)kRowTree * 2048;    // largest column transform: 2048
-constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 2048;
+constexpr int kMaxTwTable = 8192;       // per-length tables up to this length (longest column transform)
+constexpr size_t kMaxSplitTree = (size_t)kRowTree * 8192;    // largest column transform: 8192 (N up to 2^24)
+constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 4096;  // chirp length up to 2^24
 
 template <class BE> class NftPlan {
 public:
@@ -198,7 +198,7 @@ public:
     BigTwiddle big_tw(size_t N) const
     {
         BigTwiddle t;
-        t.hi = tw_table(kMaxTwTable);
+        t.hi = tw_table((size_t)1 << kFineLog2);   // exp(-2 pi i jh / 2^FINE)
         t.lo = twlo;
         t.fine_log2 = kFineLog2;
         t.shift = 2 * kFineLog2 - nft_log2(N);

@@ -926,3 +926,27 @@ def test_nse_finvscatter_arguments(capi):
     assert capi.nse_finvscatter(tm, -0.1, 1, "2SPLIT2_MODAL")[0] == 2      # eps_t
     assert capi.nse_finvscatter(np.ones((4, 7), np.complex128), 0.1, 1, "2SPLIT2_MODAL")[0] == 5   # D = 6: no power of two
     assert capi.nse_finvscatter(tm, 0.1, 1, "2SPLIT4B")[0] in (2, 5)       # no base case for this scheme
+
+
+# ---- sizes beyond round 1's D*deg <= 2^22: column transforms of 4096 and 8192, chirp length 2^24 ---------------
+@pytest.mark.parametrize("log2D,disc,bound", [(22, "2SPLIT2_MODAL", 2e-7), (21, "2SPLIT4B", 5e-8), (20, "2SPLIT8B", 2e-6),
+                                              (20, "2SPLIT6B", 2e-6)])
+def test_beyond_2p22_analytic(capi, log2D, disc, bound):
+    """The reference has no size limit (fnft__poly_fmult.c:448-455 just mallocs): D = 2^22 MODAL (top product 2^22
+    points), D = 2^21 with the default 2SPLIT4B, and D = 2^20 with the degree-12 and degree-6 schemes (top product of
+    2^24 points: column transforms of 8192, chirp length 2^24), against the closed-form Satsuma-Yajima spectrum on a
+    grid of 2^16 points, plus |a|^2 + |b|^2 = 1.  Bounds: MODAL at 2^22 has a discretization error of
+    5e-3 * (4096/D)^2 = 5e-9 in a (measured 3.8e-9) and sits at the round-off floor of 4 million factors in b and rho
+    (measured 3.5e-8); the higher-order schemes at the conditioning floor of their coefficient form (cancellation
+    in the per-sample formulas at eps_t ~ 5e-5)."""
+    D, M = 1 << log2D, 1 << 16
+    T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
+    q = S.sech_focusing(D)
+    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, discretization=disc, contspec_type="BOTH")
+    assert rc == 0, capi.last_error()
+    xi = XI[0] + np.arange(M) * (XI[1] - XI[0]) / (M - 1)
+    a, b = S.sech_focusing_analytic(xi)
+    errs = (S.rel_err(cs[M:2 * M], a), S.rel_err(cs[2 * M:], b), S.rel_err(cs[:M], b / a))
+    assert max(errs) < bound, errs
+    inv = np.abs(cs[M:2 * M]) ** 2 + np.abs(cs[2 * M:]) ** 2
+    assert np.max(np.abs(inv - 1.0)) < 100 * bound
