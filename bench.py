@@ -107,6 +107,86 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
     return out
 
 
+def bench_cfg4(args, rank, world, local_rank):
+    """BASELINE.json configs[3]: continuous spectrum AND bound states (default options: 2SPLIT4B, SUBSAMPLE_AND_REFINE, 10
+    Newton steps, norming constants) of the sech pulse at D = M = 2^20, through the drop-in fnft_nsev with HOST pointers
+    (the discrete spectrum has no device-resident entry).  One step = one call; every rank runs its own signal."""
+    import torch
+    import torch.distributed as dist
+    from fnft_amd import capi
+    import signals as S
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.rehearse_gloo else "nccl",
+                                **({} if args.rehearse_gloo else {"device_id": torch.device("cuda", local_rank)}))
+    D = M = 1 << args.log2D
+    T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
+    q = S.sech_focusing(D, amp=3.2 - 0.01 * rank)
+    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+
+    def call():
+        out = capi.fnft_nsev_ds(q, T, discretization="2SPLIT4B", M=M, XI=XI)
+        if out[0] != 0:
+            raise RuntimeError("fnft_nsev rc=%d: %s" % (out[0], capi.last_error()))
+        return out
+
+    for _ in range(warm):
+        out = call()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    stages = {}
+    for _ in range(steps):
+        out = call()
+        for name, ms in capi.discspec_stages():
+            stages[name] = stages.get(name, 0.0) + ms / steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    tt = torch.tensor([wall_ms], dtype=torch.float64, device="cpu" if (world == 1 or args.rehearse_gloo) else "cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ms_per_step = float(tt.item()) / steps
+    if rank == 0:
+        rc, bs, nc, res, cs = out
+        exact = np.array([0.7j, 1.7j, 2.7j])
+        # tree of the continuous-spectrum part (2SPLIT4B, deg 2) timed on a device plan, as in the headline workload
+        plan = capi.Plan(D, M, batch=1, discretization="2SPLIT4B", device=local_rank)
+        plan.set_timing(True)
+        dq = torch.from_numpy(q).cuda()
+        do = torch.zeros(3 * M, dtype=torch.complex128, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        tms = []
+        for _ in range(8):
+            plan.contspec_device(dq.data_ptr(), do.data_ptr(), T, XI, 1, "BOTH", 1, st)
+            torch.cuda.synchronize()
+            tms.append(plan.last_ms(0))
+        t_tree = float(np.median(tms[2:]))
+        bt = bytes_tree(D, 2)
+        line = {
+            "metric": "Msamples/s fnft_nsev contspec + bound states (D=2^%d fp64)" % args.log2D,
+            "value": round(world * D / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": steps,
+            "warmup": warm, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "fnft_nsev D=M=2^%d contspec (a,b + reflection) + bound states, norming constants "
+                                   "(default options: 2SPLIT4B, SUBSAMPLE_AND_REFINE), host-pointer drop-in call, 1 signal per GPU"
+                                   % args.log2D, "gather": "n/a"},
+            "roofline": {"bound": "hbm", "kernel": "poly_fmult2x2 tree of the continuous-spectrum part (2SPLIT4B)",
+                         "achieved": round(bt / (t_tree * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(bt / (t_tree * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                         "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
+                         "discspec_stages_ms": {k: round(v, 3) for k, v in stages.items()},
+                         "bound_states": int(bs.size),
+                         "bound_state_error": float(np.max(np.abs(np.sort_complex(bs) - exact))) if bs.size == 3 else None},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,9 +194,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2D", type=int, default=20)
     ap.add_argument("--disc", default="2SPLIT2_MODAL")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2",
                     help="cfg2: one signal D=M=2^20 per GPU (headline); cfg3: BASELINE.json configs[2], "
-                         "64 of the 512 signals D=M=2^16 per GPU; cfg5: configs[4], fnft_kdvv D=M=2^18 2SPLIT8B")
+                         "64 of the 512 signals D=M=2^16 per GPU; cfg4: configs[3], contspec + bound states at "
+                         "D=M=2^20 through the drop-in fnft_nsev (host pointers, default options); cfg5: configs[4], "
+                         "fnft_kdvv D=M=2^18 2SPLIT8B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", choices=("job", "step", "none"), default="step",
                     help="N>1: 'step' (default) = the result shards of EVERY step are gathered on rank 0 inside the "
@@ -148,6 +230,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "cfg4":
+        return bench_cfg4(args, rank, world, local_rank)
     if args.no_gather:
         args.gather = "none"
     cfg3 = args.workload == "cfg3"

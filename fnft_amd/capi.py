@@ -80,6 +80,7 @@ EXPORTED = [
     "fnft_amd_nsev_contspec_from_tm_device", "fnft__misc_resample", "fnft__poly_roots_fasteigen",
     "fnft__nse_scatter_bound_states", "fnft__poly_fmult_numel", "fnft__poly_fmult", "fnft__poly_fmult_two_polys_len",
     "fnft__poly_fmult_two_polys", "fnft__poly_fmult_two_polys2x2", "fnft__nse_finvscatter",
+    "fnft_amd_plan_last_warnings", "fnft_amd_discspec_stage_ms",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -190,6 +191,10 @@ def load(path=None):
     L.fnft__poly_fmult_two_polys2x2.argtypes = [sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, sz]
     L.fnft__nse_finvscatter.restype = i32
     L.fnft__nse_finvscatter.argtypes = [sz, vp, vp, dbl, i32, C.c_int]
+    L.fnft_amd_discspec_stage_ms.restype = dbl
+    L.fnft_amd_discspec_stage_ms.argtypes = [sz, C.c_char_p, sz]
+    L.fnft_amd_plan_last_warnings.restype = C.c_int
+    L.fnft_amd_plan_last_warnings.argtypes = [vp]
     L.fnft_amd_plan_device.restype = C.c_int
     L.fnft_amd_plan_device.argtypes = [vp]
     L.fnft_amd_current_device.restype = C.c_int
@@ -298,6 +303,18 @@ def fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="SUBSAMPLE_AND_REFINE", 
     res = nc[k:2 * k] if d == 2 else (nc[:k] if d == 1 else None)
     out = (int(rc), bs[:k].copy(), None if ncs is None else ncs.copy(), None if res is None else res.copy())
     return out + ((cs,) if M > 0 else ())
+
+
+def discspec_stages():
+    """[(stage, ms)] of this thread's last discrete-spectrum call (host wall clock)."""
+    L = load()
+    out, buf, i = [], C.create_string_buffer(64), 0
+    while True:
+        ms = float(L.fnft_amd_discspec_stage_ms(i, buf, len(buf)))
+        if ms < 0:
+            return out
+        out.append((buf.value.decode(), ms))
+        i += 1
 
 
 def poly_fmult(deg, n, p, normalize=True):

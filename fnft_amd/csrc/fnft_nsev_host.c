@@ -43,6 +43,14 @@ static FNFT_INT default_printf(const char *format, ...)
 static _Thread_local fnft_printf_ptr_t printf_ptr = default_printf;
 
 void fnft_errwarn_setprintf(fnft_printf_ptr_t p) { printf_ptr = p; }
+/* WARN(msg) of src/private/fnft__errwarn.h:36-48 for the C++ side of the library (internal) */
+void fnft_amd__warn(const char *msg, const char *func, int line)
+{
+    fnft_printf_ptr_t p = printf_ptr;
+    if (p != NULL)
+        p("FNFT Warning: %s\n in %s(%i)-%d.%d.%d%s\n", msg, func, line, FNFT_AMD_IFACE_MAJOR, FNFT_AMD_IFACE_MINOR,
+          FNFT_AMD_IFACE_PATCH, FNFT_AMD_IFACE_SUFFIX);
+}
 fnft_printf_ptr_t fnft_errwarn_getprintf(void) { return printf_ptr; }
 
 static FNFT_INT raise(FNFT_INT ec, const char *func, int line, const char *msg)

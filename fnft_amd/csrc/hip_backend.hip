@@ -10,6 +10,11 @@
 #include "../../include/fnft_amd.h"
 
 thread_local std::string g_last_error;
+// fnft__misc.c:379-380
+extern "C" void fnft_amd__warn(const char *msg, const char *func, int line);   // fnft_nsev_host.c
+static const char *const kNotBandlimitedMsg =
+    "Signal does not appear to be bandlimited. Interpolation step may be inaccurate. Try to reduce the step size, "
+    "or switch to a discretization that does not require interpolation";
 // Host-pointer entry points share cached plans and workspaces: one call at a time (SURVEY 8b allows an
 // internal mutex); device-resident plans are independent objects with their own lock.
 static std::mutex g_host_call_mtx;
@@ -134,6 +139,22 @@ void fnft_amd_plan_destroy(fnft_amd_plan_t *plan)
 FNFT_UINT fnft_amd_plan_workspace_bytes(const fnft_amd_plan_t *plan) { return plan ? plan->pl->bytes : 0; }
 
 int fnft_amd_plan_device(const fnft_amd_plan_t *plan) { return plan ? plan->device : -1; }
+
+int fnft_amd_plan_last_warnings(const fnft_amd_plan_t *plan) { return plan ? plan->pl->last_warn : 0; }
+
+// host wall-clock stages of the calling thread's last discrete-spectrum call (measurement only)
+double fnft_amd_discspec_stage_ms(FNFT_UINT i, char *name, FNFT_UINT name_cap)
+{
+    const std::vector<NftDsStage> &v = nft_ds_stages();
+    if (i >= v.size()) return -1.0;
+    if (name && name_cap) {
+        size_t n = strlen(v[i].what);
+        if (n >= name_cap) n = name_cap - 1;
+        memcpy(name, v[i].what, n);
+        name[n] = 0;
+    }
+    return v[i].ms;
+}
 
 #ifdef FNFT_AMD_TUNING
 // diagnostic builds only: tuning parameters of a plan (which: 0 = row-kernel stagger)
@@ -572,7 +593,10 @@ FNFT_INT fnft__misc_resample(const FNFT_UINT D, const FNFT_REAL eps_t, FNFT_COMP
     if (dev < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
     HipBackend be;
-    return Plan::resample_host(be, D, eps_t, q, delta, q_new);
+    int warn = 0;
+    const int rc = Plan::resample_host(be, D, eps_t, q, delta, q_new, &warn);
+    if (rc == FNFT_SUCCESS && warn) fnft_amd__warn(kNotBandlimitedMsg, "fnft__misc_resample", __LINE__);
+    return rc;
 }
 
 // include/private/fnft__poly_roots_fasteigen.h (src/private/fnft__poly_roots_fasteigen.c:29-48): all roots of
@@ -809,6 +833,8 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                                            (fnft_nsev_cstype_t)contspec_type, normalization_flag,
                                            nullptr);
     if (rc == FNFT_SUCCESS) rc = fnft_amd_plan_finish(P, nullptr);
+    // the resampler of the 4SPLIT4A/B front end warns when the spectrum has not decayed (fnft__misc.c:371-381)
+    if (fnft_amd_plan_last_warnings(P) & 1) fnft_amd__warn(kNotBandlimitedMsg, "fnft__misc_resample", __LINE__);
     if (rc == FNFT_SUCCESS && contspec && cs_len)
         if (!hip_ok(hipMemcpy(contspec, dcs, cs_len * sizeof(cplx), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
             rc = FNFT_EC_OTHER;

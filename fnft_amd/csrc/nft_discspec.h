@@ -22,16 +22,24 @@
 
 #include "nft_plan.h"
 
-// optional stage log on stderr (FNFT_AMD_DS_TIMING=1), diagnostics only
+// stage times of the last discrete-spectrum call of this thread (bench.py --workload cfg4 reports them through
+// fnft_amd_discspec_stage_ms); FNFT_AMD_DS_TIMING=1 additionally logs them on stderr
+struct NftDsStage { const char *what; double ms; };
+inline std::vector<NftDsStage> &nft_ds_stages()
+{
+    static thread_local std::vector<NftDsStage> v;
+    return v;
+}
 struct NftDsClock {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     bool on = std::getenv("FNFT_AMD_DS_TIMING") != nullptr;
+    NftDsClock() { nft_ds_stages().clear(); }
     void lap(const char *what)
     {
-        if (!on) return;
         const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[discspec] %-28s %8.3f ms\n", what,
-                     std::chrono::duration<double, std::milli>(t1 - t0).count());
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        nft_ds_stages().push_back(NftDsStage{what, ms});
+        if (on) std::fprintf(stderr, "[discspec] %-28s %8.3f ms\n", what, ms);
         t0 = t1;
     }
 };
@@ -55,6 +63,7 @@ public:
     double last_root_corr = 0.0;      // largest relative correction of the root finder's last sweep
     static constexpr int kAberthMaxSweeps = 80;
     static constexpr double kAberthTol = 4.0e-14;   // stop: largest |correction| / |root| of a sweep
+    static constexpr double kAberthFastAbove = 1.0e-3;   // last sweep's correction above this: single-precision Aberth sum
     static constexpr double kAberthFail = 1.0e-6;   // above this after the last sweep: not converged, error
     explicit NftDiscSpec(BE &be_) : be(be_) {}
 
@@ -237,6 +246,7 @@ public:
                 // estimates are double-buffered: a sweep reads zbuf[cur] everywhere and writes zbuf[cur ^ 1]
                 A.z = zbuf[cur];
                 A.z_out = zbuf[cur ^ 1];
+                A.fast = (mc > kAberthFastAbove) ? 1 : 0;   // single-precision repulsion sum while far from convergence
                 be.memset0(A.maxcorr, sizeof(unsigned long long));
                 be.template run<KAberthNewton>((int)((n + 63) / 64), 1, A);
                 be.template run<KAberthUpdate>((int)((n + 255) / 256), 1, A);

@@ -33,6 +33,12 @@ struct KResamplePhase {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_resample_phase(p); }
 };
+struct KBandCheck {
+    using Params = ResampleParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 3 * 256 * sizeof(double); }
+    static FA_DEV void body(const Params &p) { body_band_check(p); }
+};
 struct KResampleCombine {
     using Params = ResampleParams;
     static constexpr int THREADS = 256;

@@ -2244,7 +2244,37 @@ struct ResampleParams {
     int batch;
     double delta_over_span;   // delta / (Din * eps_t)
     double w0, w1;            // 0.25 + sqrt(3)/6, 0.25 - sqrt(3)/6
+    int *status;              // bit 2: "signal does not appear to be bandlimited" (body_band_check)
 };
+
+// fnft__misc.c:371-381: the resampler's own check that the spectrum has decayed -- the l2 norms (trapezoidal rule,
+// fnft__misc.c:90-112) of the two 5 % bands next to the Nyquist bin against the norm of the whole spectrum; above
+// sqrt(eps) the interpolation may be inaccurate and the reference warns.  One workgroup per signal; sets bit 2 of
+// the status word (a warning, not an error).
+FA_DEV void body_band_check(const ResampleParams &P)
+{
+    FA_LDS_DECL
+    double *red = (double *)FA_LDS_PTR;   // 3 * blockDim partial sums
+    const long long D = P.Din, Dlp = D / 20;
+    const cplx *X = P.X + (size_t)FA_BID * D;
+    double s_all = 0.0, s_lo = 0.0, s_hi = 0.0;
+    for (long long i = FA_TID; i < D; i += FA_BDIM) {
+        const double m = cnorm2(X[i]);
+        s_all += ((i == 0 || i == D - 1) ? 0.5 : 1.0) * m;
+        const long long a = i - (D / 2 - 1 - Dlp), b = i - (D / 2 + 1);   // position inside the two bands
+        if (a >= 0 && a < Dlp) s_lo += ((a == 0 || a == Dlp - 1) ? 0.5 : 1.0) * m;
+        if (b >= 0 && b < Dlp) s_hi += ((b == 0 || b == Dlp - 1) ? 0.5 : 1.0) * m;
+    }
+    red[FA_TID] = s_all; red[FA_BDIM + FA_TID] = s_lo; red[2 * FA_BDIM + FA_TID] = s_hi;
+    FA_SYNC();
+    if (FA_TID == 0) {
+        double ta = 0.0, tl = 0.0, th = 0.0;
+        for (int t = 0; t < FA_BDIM; t++) { ta += red[t]; tl += red[FA_BDIM + t]; th += red[2 * FA_BDIM + t]; }
+        // tmp = sqrt(lo + hi)/sqrt(all) > sqrt(eps)  <=>  lo + hi > eps * all   (Dlp >= 2: the reference's norm of fewer
+        // than two points is NaN and never warns)
+        if (Dlp >= 2 && (tl + th) > 2.220446049250313e-16 * ta) fa_atomic_or_i32(P.status, 4);
+    }
+}
 
 FA_DEV void body_resample_phase(const ResampleParams &P)
 {
@@ -2515,14 +2545,18 @@ struct AberthParams {
     const cplx *z;       // n estimates of this sweep (read by every workgroup)
     cplx *z_out;         // the next sweep's estimates (double buffer: no workgroup reads what another one writes)
     cplx *w;             // n Newton corrections
+    int fast;            // update kernel: single-precision Aberth sum (sweeps far from convergence)
     unsigned long long *maxcorr;   // bits of max |corr|/|z| of the sweep
 };
 
-// p(x) = sum_r x^r P_r(x^4): four independent Horner chains (plus their derivatives) per lane, the
-// coefficients staged through LDS in tiles that the workgroup loads together.  asc(k) is the
-// coefficient of x^k: x = z reads coef[n-k], x = 1/z (|z| > 1) reads coef[k].
+// p(x) = sum_r x^r P_r(x^NCH): NCH independent Horner chains (plus their derivatives and the |coefficient| chains
+// of the error scale) per lane -- the kernel runs at less than one wave per SIMD (one lane per estimate), so the
+// instruction-level parallelism of the chains is what keeps the pipeline busy -- with the coefficients staged
+// through LDS in tiles that the workgroup loads together.  asc(k) is the coefficient of x^k: x = z reads
+// coef[n-k], x = 1/z (|z| > 1) reads coef[k].
 template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
 {
+    constexpr int NCH = 8;
     FA_LDS_DECL
     cplx *tile = (cplx *)FA_LDS_PTR;
     double *tabs = (double *)(tile + 2 * TILE);   // |coefficient| of the same tile, both orientations
@@ -2532,15 +2566,24 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
     const cplx z = act ? P.z[k] : cmake(0.5, 0.0);
     const bool inside = cnorm2(z) <= 1.0;
     const cplx x = inside ? z : c_div(cmake(1.0, 0.0), z);
-    const cplx x2 = x * x, w = x2 * x2;
-    const double ax = sqrt(cnorm2(x)), aw = (ax * ax) * (ax * ax);
-    cplx p0 = cmake(0.0, 0.0), p1 = p0, p2 = p0, p3 = p0, d0 = p0, d1 = p0, d2 = p0, d3 = p0;
-    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;   // the same four chains on |coefficients| and |x|: error scale
-    // powers run from the top block (m = Mtop) down to m = 0; block m holds powers 4m .. 4m+3
-    const long long Mtop = n / 4;
-    for (long long mhi = Mtop; mhi >= 0; mhi -= TILE / 4) {
-        const long long mlo = (mhi - TILE / 4 + 1 > 0) ? mhi - TILE / 4 + 1 : 0;
-        const long long kbase = 4 * mlo;            // lowest power held by this tile
+    cplx xp[NCH];               // x^0 .. x^(NCH-1)
+    xp[0] = cmake(1.0, 0.0);
+#pragma unroll
+    for (int c = 1; c < NCH; c++) xp[c] = xp[c - 1] * x;
+    const cplx w = xp[NCH - 1] * x;   // x^NCH
+    const double ax = sqrt(cnorm2(x));
+    double aw = 1.0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) aw *= ax;
+    cplx pc[NCH], dc[NCH];
+    double ec[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) { pc[c] = cmake(0.0, 0.0); dc[c] = cmake(0.0, 0.0); ec[c] = 0.0; }
+    // powers run from the top block (m = Mtop) down to m = 0; block m holds powers NCH*m .. NCH*m + NCH-1
+    const long long Mtop = n / NCH;
+    for (long long mhi = Mtop; mhi >= 0; mhi -= TILE / NCH) {
+        const long long mlo = (mhi - TILE / NCH + 1 > 0) ? mhi - TILE / NCH + 1 : 0;
+        const long long kbase = NCH * mlo;            // lowest power held by this tile
         FA_SYNC();
         for (int t = FA_TID; t < TILE; t += FA_BDIM) {
             const long long kk = kbase + t;
@@ -2555,28 +2598,33 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
         FA_SYNC();
         const int off = inside ? 0 : 1;
         for (long long m = mhi; m >= mlo; m--) {
-            const int t = (int)(4 * (m - mlo));
-            d0 = d0 * w + p0; p0 = p0 * w + tile[2 * t + off];
-            d1 = d1 * w + p1; p1 = p1 * w + tile[2 * (t + 1) + off];
-            d2 = d2 * w + p2; p2 = p2 * w + tile[2 * (t + 2) + off];
-            d3 = d3 * w + p3; p3 = p3 * w + tile[2 * (t + 3) + off];
-            e0 = fma(e0, aw, tabs[2 * t + off]);
-            e1 = fma(e1, aw, tabs[2 * (t + 1) + off]);
-            e2 = fma(e2, aw, tabs[2 * (t + 2) + off]);
-            e3 = fma(e3, aw, tabs[2 * (t + 3) + off]);
+            const int t = (int)(NCH * (m - mlo));
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                dc[c] = dc[c] * w + pc[c];
+                pc[c] = pc[c] * w + tile[2 * (t + c) + off];
+                ec[c] = fma(ec[c], aw, tabs[2 * (t + c) + off]);
+            }
         }
     }
     if (!act) return;
-    // p = P0 + x P1 + x^2 P2 + x^3 P3;  p' = P1 + 2x P2 + 3x^2 P3 + 4x^3 (P0' + x P1' + x^2 P2' + x^3 P3')
-    const cplx x3 = x2 * x;
-    const cplx p = p0 + x * p1 + x2 * p2 + x3 * p3;
-    const cplx dsum = d0 + x * d1 + x2 * d2 + x3 * d3;
-    const cplx dp = p1 + (x * p2) * 2.0 + (x2 * p3) * 3.0 + (x3 * dsum) * 4.0;
+    // p = sum_c x^c P_c;  p' = sum_c c x^(c-1) P_c + NCH x^(NCH-1) sum_c x^c P_c'
+    cplx p = pc[0], dsum = dc[0], dp = cmake(0.0, 0.0);
+    double escale = ec[0], axp = 1.0;
+#pragma unroll
+    for (int c = 1; c < NCH; c++) {
+        p = p + xp[c] * pc[c];
+        dsum = dsum + xp[c] * dc[c];
+        dp = dp + (xp[c - 1] * pc[c]) * (double)c;
+        axp *= ax;
+        escale = fma(axp, ec[c], escale);
+    }
+    dp = dp + (xp[NCH - 1] * dsum) * (double)NCH;
     // |p(x)| at the level of its own evaluation error (running error bound of Horner's scheme, statistical
     // sqrt(n) growth): the estimate is a root to working accuracy and is left alone -- without this, roots of
     // an ill-conditioned polynomial keep receiving corrections of the size of the noise and never "converge"
-    const double escale = e0 + ax * (e1 + ax * (e2 + ax * e3));
     const double noise = 2.220446049250313e-16 * (2.0 * sqrt((double)n) + 2.0) * escale;
+    const cplx x2 = xp[2];
     cplx wv;
     if (cnorm2(p) <= noise * noise) {
         wv = cmake(0.0, 0.0);
@@ -2591,18 +2639,20 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
     P.w[k] = wv;
 }
 
-// distance vector for the Aberth sum with two repairs: the own term counts as 1/(1 + 0i) (taken out by the
-// caller), and an estimate that COINCIDES with another one -- 1/0 otherwise, after which both would freeze --
-// is treated as if it sat a tiny step away, in opposite directions for the two members of the pair
-FA_DEV cplx aberth_dist(cplx zk, cplx zj, long long k, long long j)
+// One term 1/(zk - zj) = conj(d)/|d|^2 of the Aberth sum, branch-free: the own term counts as 1/(1 + 0i) (taken
+// out by the caller); an estimate that COINCIDES with another one contributes nothing here (instead of 1/0, after
+// which both would freeze) and raises `hit`, and the caller then pushes this estimate a tiny, index-dependent step
+// away so that the pair separates.
+FA_DEV cplx aberth_term(cplx zk, cplx zj, bool own, bool &hit)
 {
-    if (j == k) return cmake(1.0, 0.0);
     cplx d = zk - zj;
-    if (d.x == 0.0 && d.y == 0.0) {
-        const double h = 1.0e-8 * (1.0 + sqrt(cnorm2(zk)));
-        d = (k < j) ? cmake(h, 0.5 * h) : cmake(-h, -0.5 * h);
-    }
-    return d;
+    d = own ? cmake(1.0, 0.0) : d;
+    double n2 = cnorm2(d);
+    const bool zero = (n2 == 0.0);
+    hit = hit || zero;
+    n2 = zero ? 1.0 : n2;
+    const double inv = 1.0 / n2;
+    return cmake(d.x * inv, -d.y * inv);
 }
 template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
 {
@@ -2612,36 +2662,71 @@ template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
     const bool act = k < P.n;
     const cplx zk = act ? P.z[k] : cmake(0.0, 0.0);
     cplx s = cmake(0.0, 0.0);
-    for (long long j0 = 0; j0 < P.n; j0 += TILE) {
-        FA_SYNC();
-        if (j0 + FA_TID < P.n) tile[FA_TID] = P.z[j0 + FA_TID];
-        FA_SYNC();
-        const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
-        if (act) {
-            // 1/(zk - zj) = conj(d)/|d|^2
-            cplx s1 = cmake(0.0, 0.0);
-            int j = 0;
-            for (; j + 1 < lim; j += 2) {
-                const cplx da = aberth_dist(zk, tile[j], k, j0 + j), db = aberth_dist(zk, tile[j + 1], k, j0 + j + 1);
-                const double ia = 1.0 / cnorm2(da), ib = 1.0 / cnorm2(db);
-                s = s + cmake(da.x * ia, -da.y * ia);
-                s1 = s1 + cmake(db.x * ib, -db.y * ib);
+    bool hit = false;   // this estimate coincides with another one
+    if (P.fast) {
+        // far from convergence (corrections of 1e-3 and more) the repulsion sum only steers the estimates apart:
+        // single precision is plenty, and it runs at several times the rate of the double-precision divisions
+        float sx = 0.f, sy = 0.f, tx = 0.f, ty = 0.f;
+        const float zx = (float)zk.x, zy = (float)zk.y;
+        float *tf = (float *)tile;
+        for (long long j0 = 0; j0 < P.n; j0 += TILE) {
+            FA_SYNC();
+            if (j0 + FA_TID < P.n) {
+                const cplx zj = P.z[j0 + FA_TID];
+                tf[2 * FA_TID] = (float)zj.x;
+                tf[2 * FA_TID + 1] = (float)zj.y;
             }
-            if (j < lim) {
-                const cplx da = aberth_dist(zk, tile[j], k, j0 + j);
-                const double ia = 1.0 / cnorm2(da);
-                s = s + cmake(da.x * ia, -da.y * ia);
+            FA_SYNC();
+            const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
+            if (act) {
+                int j = 0;
+                for (; j + 1 < lim; j += 2) {
+                    float ax = zx - tf[2 * j], ay = zy - tf[2 * j + 1];
+                    float bx = zx - tf[2 * j + 2], by = zy - tf[2 * j + 3];
+                    float na = ax * ax + ay * ay, nb = bx * bx + by * by;
+                    // own term and exact coincidences contribute nothing (the double-precision sweeps separate them)
+                    const float ia = (na > 0.f) ? 1.0f / na : 0.f, ib = (nb > 0.f) ? 1.0f / nb : 0.f;
+                    sx += ax * ia; sy -= ay * ia;
+                    tx += bx * ib; ty -= by * ib;
+                }
+                if (j < lim) {
+                    const float ax = zx - tf[2 * j], ay = zy - tf[2 * j + 1];
+                    const float na = ax * ax + ay * ay;
+                    const float ia = (na > 0.f) ? 1.0f / na : 0.f;
+                    sx += ax * ia; sy -= ay * ia;
+                }
             }
-            s = s + s1;
         }
+        s = cmake((double)sx + (double)tx, (double)sy + (double)ty);
+    } else {
+        for (long long j0 = 0; j0 < P.n; j0 += TILE) {
+            FA_SYNC();
+            if (j0 + FA_TID < P.n) tile[FA_TID] = P.z[j0 + FA_TID];
+            FA_SYNC();
+            const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
+            if (act) {
+                cplx s1 = cmake(0.0, 0.0);
+                int j = 0;
+                for (; j + 1 < lim; j += 2) {
+                    s = s + aberth_term(zk, tile[j], j0 + j == k, hit);
+                    s1 = s1 + aberth_term(zk, tile[j + 1], j0 + j + 1 == k, hit);
+                }
+                if (j < lim) s = s + aberth_term(zk, tile[j], j0 + j == k, hit);
+                s = s + s1;
+            }
+        }
+        s = s - cmake(1.0, 0.0);   // the own term was counted as 1/(1 + 0i)
     }
-    s = s - cmake(1.0, 0.0);
     FA_SYNC();
     double rel = 0.0;
     if (act) {
         const cplx w = P.w[k];
         cplx corr = c_div(w, cmake(1.0, 0.0) - w * s);
         const double az0 = sqrt(cnorm2(zk));
+        if (hit) {   // coincident estimates: separate them (different steps for different k)
+            const double h = 1.0e-8 * (1.0 + az0);
+            corr = corr + cmake(h * (1.0 + (double)(k & 7)), -0.5 * h * (1.0 + (double)((k >> 3) & 7)));
+        }
         if (!(corr.x == corr.x) || !(corr.y == corr.y) || fabs(corr.x) > 1.0e300 || fabs(corr.y) > 1.0e300) {
             // degenerate step (0/0, overflow): move the estimate a little instead of freezing it; the sweep
             // then does not count as converged

@@ -166,6 +166,7 @@ public:
     int kappa_run = 1;
     unsigned long long *dbg_stamps = nullptr;   // -DFNFT_AMD_STAMPS builds: 16 u64 per wave of the row kernel
     int stamp_level = -1;                        // split level (0 = first) whose row kernel is stamped
+    int last_warn = 0;       // bit 0: the resampler found the signal not band-limited (set by read_status)
     int tune_stagger = 0;    // row kernel start delay of the second half of a one-round grid (BigLevel::stagger)
     int dbg_flags = 0;       // timing ablation: only builds with -DFNFT_AMD_ABLATION ever set it (hip_backend.hip)
 
@@ -320,6 +321,7 @@ public:
             Tsub[1] = T[1];
             return run_coeffs(d_q, kdv ? rneg : nullptr, eps_in, kappa);
         }
+        be.memset0(status, 4 * sizeof(int));   // the resampler below may set the "not band-limited" bit
         const size_t Dsub = D / 2;
         Tsub[0] = T[0];
         Tsub[1] = T[0] + (double)((Dsub - 1) * nskip) * eps_in;
@@ -349,6 +351,8 @@ public:
         R.delta_over_span = scl * (double)nskip / (double)Din;
         R.w0 = 0.25 + scl;
         R.w1 = 0.25 - scl;
+        R.status = status;
+        be.template run<KBandCheck>((int)batch, 1, R);     // fnft__misc.c:371-381 (warning only)
         be.template run<KResamplePhase>((int)((batch * Din + 255) / 256), 1, R);
         // inverse DFTs (:395-399), then the weighted pairs (:493-499)
         C.poly = rsX12;
@@ -358,13 +362,13 @@ public:
         rc = run_chirp(C);
         if (rc != NFT_SUCCESS) return rc;
         be.template run<KResampleCombine>((int)((batch * Dsub + 255) / 256), 1, R);
-        return run_coeffs(qpre, nullptr, eps_t, kappa);
+        return run_coeffs(qpre, nullptr, eps_t, kappa, false);
     }
 
     // ---- level 0 from samples (fnft__akns_fscatter.c:116-917) --------------------------------
-    int run_coeffs(const void *d_q, const void *d_r, double eps_t, int kappa)
+    int run_coeffs(const void *d_q, const void *d_r, double eps_t, int kappa, bool clear_status = true)
     {
-        be.memset0(status, 4 * sizeof(int));
+        if (clear_status) be.memset0(status, 4 * sizeof(int));
         CoeffParams p;
         p.q = (const cplx *)d_q;
         p.r = (const cplx *)d_r;
@@ -777,7 +781,7 @@ public:
     // stand-alone band-limited shift of one host signal by delta (fnft__misc.c:326-407): DFT of any length
     // (chirp kernels in DFT mode), phase ramp exp(2 pi i delta f), inverse DFT, 1/D
     static int resample_host(BE &be, size_t Dn, double eps_t, const std::complex<double> *q, double delta,
-                             std::complex<double> *q_new)
+                             std::complex<double> *q_new, int *warn_not_bandlimited = nullptr)
     {
         NftPlan pl(be, 2, 0, 1, 0, 1);  // only the twiddle tables of the plan are used
         size_t L = nft_nextpow2(2 * Dn - 1);
@@ -814,6 +818,8 @@ public:
                 R.Din = (long long)Dn; R.Dsub = (long long)Dn; R.nskip = 1;
                 R.batch = 1;
                 R.delta_over_span = delta / ((double)Dn * eps_t);    // freq[i]*delta, :383-393
+                R.status = dstatus;
+                be.template run<KBandCheck>(1, 1, R);                // :371-381
                 be.template run<KResamplePhase>((int)((Dn + 255) / 256), 1, R);
                 C.poly = dX12;
                 C.npoly = 2;
@@ -822,8 +828,11 @@ public:
                 rc = pl.run_chirp(C);                               // inverse DFTs of the -delta and +delta copies
             }
             if (rc == NFT_SUCCESS) {
+                int hst[4] = {0, 0, 0, 0};
+                be.d2h(hst, dstatus, sizeof(hst));
                 be.d2h(q_new, dQ12 + Dn, Dn * sizeof(cplx));        // the +delta copy
                 rc = be.sync();
+                if (warn_not_bandlimited) *warn_not_bandlimited = (hst[0] & 4) ? 1 : 0;
                 const double inv = 1.0 / (double)Dn;                // :395-399
                 if (rc == NFT_SUCCESS)
                     for (size_t i = 0; i < Dn; i++) q_new[i] *= inv;
@@ -841,6 +850,7 @@ public:
         be.d2h(h, status, sizeof(h));
         const int rc = be.sync();
         if (rc != NFT_SUCCESS) return rc;
+        last_warn = (h[0] & 4) ? 1 : 0;            // fnft__misc.c:371-381: not an error
         if (h[0] & 1) return -NFT_EC_OTHER;        // fnft__akns_fscatter.c:122-126 via CHECK_RETCODE
         if (h[0] & 2) return -NFT_EC_DIV_BY_ZERO;  // fnft_nsev.c:850-853 via CHECK_RETCODE
         return NFT_SUCCESS;

@@ -294,6 +294,13 @@ FNFT_INT fnft_amd_plan_create_sub(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT
 void fnft_amd_plan_destroy(fnft_amd_plan_t *plan);
 /* Bytes of HBM the plan holds. */
 FNFT_UINT fnft_amd_plan_workspace_bytes(const fnft_amd_plan_t *plan);
+/* Warnings of the last finished call (after fnft_amd_plan_finish): bit 0 = the band-limited resampler of the
+ * 4SPLIT4A/B front end found the signal's spectrum not decayed (the reference's "Signal does not appear to be
+ * bandlimited" warning, src/private/fnft__misc.c:371-381; the drop-in fnft_nsev prints it through the printf hook). */
+int fnft_amd_plan_last_warnings(const fnft_amd_plan_t *plan);
+/* Measurement hook: stage i of the calling thread's last discrete-spectrum computation (the bound-state part of
+ * fnft_nsev) as (name, host wall-clock ms); -1 past the last stage. */
+double fnft_amd_discspec_stage_ms(FNFT_UINT i, char *name, FNFT_UINT name_cap);
 /* Device the plan's workspace lives on (-1 for NULL). */
 int fnft_amd_plan_device(const fnft_amd_plan_t *plan);
 

@@ -950,3 +950,36 @@ def test_beyond_2p22_analytic(capi, log2D, disc, bound):
     assert max(errs) < bound, errs
     inv = np.abs(cs[M:2 * M]) ** 2 + np.abs(cs[2 * M:]) ** 2
     assert np.max(np.abs(inv - 1.0)) < 100 * bound
+
+
+def test_not_bandlimited_warning(capi):
+    """src/private/fnft__misc.c:371-381: the resampler of the 4SPLIT4A/B front end warns (a message, no return code) when
+    the 5 % bands next to the Nyquist bin hold more than sqrt(eps) of the spectrum's l2 norm -- a rectangular pulse does,
+    the smooth sech pulse does not; the stand-alone fnft__misc_resample seam says the same."""
+    import ctypes as C
+    L = capi.load()
+    seen = []
+    CB = C.CFUNCTYPE(C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p)
+
+    def hook(fmt, msg, func, line, a, b, c, suffix):
+        seen.append((fmt, msg, func))
+        return 0
+
+    cb = CB(hook)
+    L.fnft_errwarn_setprintf(C.cast(cb, C.c_void_p))
+    try:
+        D, M = 1024, 32
+        T, XI = [-25.0, 25.0], [-1.4, 1.6]
+        rect = np.where(np.abs(S.tgrid(T, D)) < 3.0, 1.5 + 0j, 0j)
+        rc, _ = capi.fnft_nsev(S.sech_focusing(D), T, M, XI, kappa=1, discretization="4SPLIT4B", contspec_type="BOTH")
+        assert rc == 0 and not seen                       # smooth pulse: band-limited to working accuracy
+        rc, _ = capi.fnft_nsev(rect, T, M, XI, kappa=1, discretization="4SPLIT4B", contspec_type="BOTH")
+        assert rc == 0                                    # a warning is not an error
+        assert len(seen) == 1 and seen[0][0].startswith(b"FNFT Warning: %s")
+        assert b"does not appear to be bandlimited" in seen[0][1] and seen[0][2] == b"fnft__misc_resample"
+        rc, _ = capi.fnft_nsev(rect, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="BOTH")
+        assert rc == 0 and len(seen) == 1                 # no resampling, no warning
+        rc, _ = capi.misc_resample(rect, (T[1] - T[0]) / (D - 1), 0.01)
+        assert rc == 0 and len(seen) == 2
+    finally:
+        L.fnft_errwarn_setprintf(None)
