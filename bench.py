@@ -179,7 +179,9 @@ def bench_cfg4(args, rank, world, local_rank):
                          "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
                          "discspec_stages_ms": {k: round(v, 3) for k, v in stages.items()},
                          "bound_states": int(bs.size),
-                         "bound_state_error": float(np.max(np.abs(np.sort_complex(bs) - exact))) if bs.size == 3 else None},
+                         "bound_state_error": (float(max(np.abs(bs[:, None] - exact[None, :]).min(axis=0).max(),
+                                                          np.abs(bs[:, None] - exact[None, :]).min(axis=1).max()))
+                                               if bs.size else None)},
             "cpu_baseline": None,
         }
         print(json.dumps(line), flush=True)
