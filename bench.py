@@ -202,6 +202,7 @@ def main():
                          "D=M=2^20 through the drop-in fnft_nsev (host pointers, default options); cfg5: configs[4], "
                          "fnft_kdvv D=M=2^18 2SPLIT8B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-transforms-in-flight rate")
     ap.add_argument("--gather", choices=("job", "step", "none"), default="step",
                     help="N>1: 'step' (default) = the result shards of EVERY step are gathered on rank 0 inside the "
                          "timed region (RCCL, overlapped with the next step's compute); 'job' = only the last "
@@ -394,6 +395,33 @@ def main():
                     raise RuntimeError("fnft_nsev (host pointers) rc=%d: %s" % (rch, capi.last_error()))
             roof["host_call_ms"] = round(float(np.median(th[1:])), 4)
             roof["host_call_Msamples_per_s"] = round(D / (roof["host_call_ms"] * 1e-3) / 1e6, 1)
+        if world == 1 and not args.no_pipelined:
+            # (iii) two transforms in flight: a second plan on a second stream, steps alternating between them
+            # (successive signals of a receiver; independent work, every step still one whole transform).
+            # Informational -- `value` is the one-transform-at-a-time rate above.
+            plan2 = (capi.KdvvPlan if cfg5 else capi.Plan)(D, M, batch=B, discretization=args.disc, device=local_rank)
+            s2 = torch.cuda.Stream()
+            lanes = [(plan, stream, outs[0]), (plan2, s2.cuda_stream, outs[1])]
+
+            def piped(i):
+                pl, st, ob = lanes[i % 2]
+                if cfg5:
+                    return pl.contspec_device(dq.data_ptr(), ob.data_ptr(), T, XI, stream=st)
+                return pl.contspec_device(dq.data_ptr(), ob.data_ptr(), T, XI, kappa=1, contspec_type="BOTH",
+                                          normalization_flag=1, stream=st)
+            for i in range(4):
+                piped(i)
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            for i in range(args.steps):
+                if piped(i) != 0:
+                    raise RuntimeError("pipelined step: %s" % capi.last_error())
+            torch.cuda.synchronize()
+            tp = (time.perf_counter() - tp0) * 1e3 / args.steps
+            if plan2.finish(s2.cuda_stream) != 0:
+                raise RuntimeError("pipelined steps, device status: %s" % capi.last_error())
+            roof["two_in_flight"] = {"ms_per_step": round(tp, 4), "Msamples_per_s": round(B * D / (tp * 1e-3) / 1e6, 1)}
+            plan2.close()
         if not args.no_cpu_baseline and world == 1:   # the CPU checker is timed at N = 1 only
             from oracle import load_oracle
             orc = load_oracle()

@@ -28,6 +28,16 @@
 #define FA_LDS_PTR (fa_lds_raw)
 FA_DEV void fa_atomic_max_u64(unsigned long long *p, unsigned long long v) { atomicMax(p, v); }
 FA_DEV void fa_atomic_add_i32(int *p, int v) { atomicAdd(p, v); }
+// slot in a list that the lanes with `want` append to (every lane of the wave calls this): ONE atomic per wave
+FA_DEV int fa_wave_append_slot(int *cnt, bool want)
+{
+    const unsigned long long mask = __ballot(want);
+    const int lane = (int)(threadIdx.x & 63);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(cnt, __popcll(mask));
+    base = __builtin_amdgcn_readfirstlane(base);
+    return base + __popcll(mask & ((1ull << lane) - 1ull));
+}
 // max over the 64 lanes of the wave, then ONE atomic per wave (do not rely on the compiler's
 // atomic optimizer: without the reduction 2^20 lanes hit a handful of addresses)
 FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
@@ -59,6 +69,9 @@ FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
     return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
+// hardware reciprocals (v_rcp_f64 / v_rcp_f32): starting values, refine where accuracy matters
+FA_DEV double fa_rcp_approx(double x) { return __builtin_amdgcn_rcp(x); }
+FA_DEV float fa_rcp_approx_f32(float x) { return __builtin_amdgcn_rcpf(x); }
 FA_DEV void fa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 // start delay of part of a grid: n sleep periods of ~1024 clocks for the waves that are `late`
 FA_DEV void fa_stagger(int n, bool late)
@@ -102,6 +115,7 @@ FA_DEV void fa_atomic_max_u64(unsigned long long *p, unsigned long long v)
     while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 FA_DEV void fa_atomic_add_i32(int *p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+FA_DEV int fa_wave_append_slot(int *cnt, bool want) { return want ? __atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED) : 0; }
 FA_DEV void fa_wave_atomic_max_f64bits(unsigned long long *p, double v)
 {
     union { double d; unsigned long long u; } cv;
@@ -123,6 +137,8 @@ FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
     return x;
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+FA_DEV double fa_rcp_approx(double x) { return 1.0 / x; }
+FA_DEV float fa_rcp_approx_f32(float x) { return 1.0f / x; }
 FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
 FA_DEV double fa_uniform(double x) { return x; }
 FA_DEV void fa_stagger(int, bool) {}

@@ -23,7 +23,7 @@
 #include "nft_plan.h"
 
 // stage times of the last discrete-spectrum call of this thread (bench.py --workload cfg4 reports them through
-// fnft_amd_discspec_stage_ms); FNFT_AMD_DS_TIMING=1 additionally logs them on stderr
+// fnft_amd_discspec_stage_ms); the product library reads no environment variable
 struct NftDsStage { const char *what; double ms; };
 inline std::vector<NftDsStage> &nft_ds_stages()
 {
@@ -32,14 +32,12 @@ inline std::vector<NftDsStage> &nft_ds_stages()
 }
 struct NftDsClock {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    bool on = std::getenv("FNFT_AMD_DS_TIMING") != nullptr;
     NftDsClock() { nft_ds_stages().clear(); }
     void lap(const char *what)
     {
         const auto t1 = std::chrono::steady_clock::now();
         const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         nft_ds_stages().push_back(NftDsStage{what, ms});
-        if (on) std::fprintf(stderr, "[discspec] %-28s %8.3f ms\n", what, ms);
         t0 = t1;
     }
 };
@@ -147,7 +145,9 @@ public:
         B.ups = P.ups;
         B.T0 = P.T[0]; B.T1 = P.T[1]; B.eps = P.eps_t;
         B.K = (int)K;
-        size_t L = (P.Deff + 4095) / 4096;
+        // chunks of >= 16 samples, about 16384 of them on a long signal (one lane each in the chunk kernels;
+        // the combine kernels take them in runs of nchunk/256 per lane)
+        size_t L = (P.Deff + 16383) / 16384;
         if (L < 16) L = 16;
         if (L % 2) L++;
         B.L = (int)L;
@@ -170,15 +170,15 @@ public:
             be.h2d(d_lam, lam, K * sizeof(cplx));
             B.lam = d_lam; B.cm = cm; B.bnd = bnd; B.bndp = bndp; B.PHI = PHI; B.best = best;
             B.a = d_out; B.aprime = d_out + K; B.b = d_out + 2 * K;
-            const int gx = (B.nchunk + 63) / 64, ge = (int)((K + 63) / 64);
+            const int gx = (B.nchunk + 63) / 64;
             be.template run<KBsChunk<false>>(gx, (int)K, B);
-            be.template run<KBsCombine<false>>(ge, 1, B);
+            be.template run<KBsCombine<false>>((int)K, 1, B);
             if (!skip_b) {
                 be.template run<KBsPhi>(gx, (int)K, B);
                 be.template run<KBsChunk<true>>(gx, (int)K, B);
-                be.template run<KBsCombine<true>>(ge, 1, B);
+                be.template run<KBsCombine<true>>((int)K, 1, B);
                 be.template run<KBsMetric>(gx, (int)K, B);
-                be.template run<KBsPick>(ge, 1, B);
+                be.template run<KBsPick>((int)K, 1, B);
             }
             std::vector<cd> h(3 * K);
             be.d2h(h.data(), d_out, (skip_b ? 2 : 3) * K * sizeof(cplx));
@@ -234,29 +234,63 @@ public:
         AberthParams A;
         A.coef = d_coef;
         A.n = (long long)n;
+        // segments of the two O(n^2) kernels: about 2048 workgroups of 256 lanes per launch.  The segment arrays
+        // hold kSegCap values per estimate; with fewer estimates left, a sweep uses more segments.
+        constexpr size_t kSegCap = 16;
         cplx *zbuf[2] = {(cplx *)be.alloc(n * sizeof(cplx)), (cplx *)be.alloc(n * sizeof(cplx))};
-        A.w = (cplx *)be.alloc(n * sizeof(cplx));
-        A.maxcorr = (unsigned long long *)be.alloc(sizeof(unsigned long long));
-        if (!zbuf[0] || !zbuf[1] || !A.w || !A.maxcorr) rc = NFT_EC_NOMEM;
-        int cur = 0;
+        int *ibuf[2] = {(int *)be.alloc(n * sizeof(int)), (int *)be.alloc(n * sizeof(int))};
+        A.pp = (cplx *)be.alloc(kSegCap * n * sizeof(cplx));
+        A.pd = (cplx *)be.alloc(kSegCap * n * sizeof(cplx));
+        A.ps = (cplx *)be.alloc(kSegCap * n * sizeof(cplx));
+        A.pe = (double *)be.alloc(kSegCap * n * sizeof(double));
+        A.hit = (int *)be.alloc(n * sizeof(int));
+        // {bits of the largest correction, number of estimates that moved}
+        unsigned long long *d_state = (unsigned long long *)be.alloc(2 * sizeof(unsigned long long));
+        A.maxcorr = d_state;
+        A.cnt = (int *)(d_state + 1);
+        if (!zbuf[0] || !zbuf[1] || !ibuf[0] || !ibuf[1] || !A.pp || !A.pd || !A.ps || !A.pe || !A.hit || !d_state)
+            rc = NFT_EC_NOMEM;
+        int cur = 0, icur = 0;
         double mc = 1.0;
+        size_t na = n;
         if (rc == NFT_SUCCESS) {
+            std::vector<int> ident(n);
+            for (size_t i = 0; i < n; i++) ident[i] = (int)i;
             be.h2d(zbuf[0], z.data(), n * sizeof(cplx));
-            for (int it = 0; it < kAberthMaxSweeps; it++) {
+            be.h2d(zbuf[1], z.data(), n * sizeof(cplx));
+            be.h2d(ibuf[0], ident.data(), n * sizeof(int));
+            be.memset0(A.hit, n * sizeof(int));
+            for (int it = 0; it < kAberthMaxSweeps && na > 0; it++) {
                 // estimates are double-buffered: a sweep reads zbuf[cur] everywhere and writes zbuf[cur ^ 1]
                 A.z = zbuf[cur];
                 A.z_out = zbuf[cur ^ 1];
+                A.idx = ibuf[icur];
+                A.idx_out = ibuf[icur ^ 1];
+                A.na = (long long)na;
+                const int gx = (int)((na + 255) / 256);
+                size_t S = (2048 + (size_t)gx - 1) / (size_t)gx;
+                if (S > 64) S = 64;
+                if (S * na > kSegCap * n) S = kSegCap * n / na;
+                if (n < 128 || S < 1) S = 1;
+                A.S = (int)S;
+                A.L = (long long)(((n + 1 + S - 1) / S + 7) / 8 * 8);
+                A.J = (long long)((n + S - 1) / S);
                 A.fast = (mc > kAberthFastAbove) ? 1 : 0;   // single-precision repulsion sum while far from convergence
-                be.memset0(A.maxcorr, sizeof(unsigned long long));
-                be.template run<KAberthNewton>((int)((n + 63) / 64), 1, A);
-                be.template run<KAberthUpdate>((int)((n + 255) / 256), 1, A);
+                be.memset0(d_state, 2 * sizeof(unsigned long long));
+                be.template run<KAberthNewton>(gx, (int)S, A);
+                be.template run<KAberthSum>(gx, (int)S, A);
+                be.template run<KAberthApply>(gx, 1, A);
                 cur ^= 1;
-                unsigned long long bits = 0;
-                be.d2h(&bits, A.maxcorr, sizeof(bits));
+                icur ^= 1;
+                unsigned long long st[2] = {0, 0};
+                be.d2h(st, d_state, sizeof(st));
                 rc = be.sync();
                 if (rc != NFT_SUCCESS) break;
-                std::memcpy(&mc, &bits, sizeof(mc));
-                if (std::getenv("FNFT_AMD_DS_TIMING")) std::fprintf(stderr, "[aberth] n=%zu sweep %d max rel corr %.3e\n", n, it, mc);
+                std::memcpy(&mc, &st[0], sizeof(mc));
+                na = (size_t)(st[1] & 0xffffffffull);
+#ifdef FNFT_AMD_TUNING
+                std::fprintf(stderr, "[aberth] n=%zu sweep %d max rel corr %.3e, %zu estimates moved, S=%zu\n", n, it, mc, na, S);
+#endif
                 if (mc < kAberthTol) break;
             }
             if (rc == NFT_SUCCESS) {
@@ -264,7 +298,8 @@ public:
                 rc = be.sync();
             }
         }
-        be.free(zbuf[0]); be.free(zbuf[1]); be.free(A.w); be.free(A.maxcorr);
+        be.free(zbuf[0]); be.free(zbuf[1]); be.free(ibuf[0]); be.free(ibuf[1]);
+        be.free(A.pp); be.free(A.pd); be.free(A.ps); be.free(A.pe); be.free(A.hit); be.free(d_state);
         last_root_corr = mc;
         if (rc == NFT_SUCCESS && !(mc < kAberthTol)) {
             // the sweep limit was reached: the reference's QR (eiscor) reports non-convergence as an error of

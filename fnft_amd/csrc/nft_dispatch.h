@@ -53,8 +53,8 @@ template <bool BACKWARD> struct KBsChunk {
 };
 template <bool BACKWARD> struct KBsCombine {
     using Params = BsParams;
-    static constexpr int THREADS = 64;
-    static constexpr size_t lds_bytes() { return 0; }
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 256 * 12 * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_bs_combine<BACKWARD>(p); }
 };
 struct KBsPhi {
@@ -71,21 +71,27 @@ struct KBsMetric {
 };
 struct KBsPick {
     using Params = BsParams;
-    static constexpr int THREADS = 64;
-    static constexpr size_t lds_bytes() { return 0; }
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 256 * (sizeof(double) + sizeof(int)); }
     static FA_DEV void body(const Params &p) { body_bs_pick(p); }
 };
 struct KAberthNewton {
     using Params = AberthParams;
-    static constexpr int THREADS = 64;
-    static constexpr size_t lds_bytes() { return 2 * 1024 * (sizeof(cplx) + sizeof(double)); }
-    static FA_DEV void body(const Params &p) { body_aberth_newton<1024>(p); }
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 2 * 512 * (sizeof(cplx) + sizeof(double)); }
+    static FA_DEV void body(const Params &p) { body_aberth_newton<512>(p); }
 };
-struct KAberthUpdate {
+struct KAberthSum {
     using Params = AberthParams;
     static constexpr int THREADS = 256;
     static constexpr size_t lds_bytes() { return 256 * sizeof(cplx); }
-    static FA_DEV void body(const Params &p) { body_aberth_update<256>(p); }
+    static FA_DEV void body(const Params &p) { body_aberth_sum<256>(p); }
+};
+struct KAberthApply {
+    using Params = AberthParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_aberth_apply(p); }
 };
 template <int DEG> struct LeafCfg {
     static constexpr int SPT = (DEG == 1) ? 8 : (DEG == 2 ? 4 : 2);

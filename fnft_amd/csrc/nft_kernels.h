@@ -2408,48 +2408,111 @@ template <bool BACKWARD> FA_DEV void body_bs_chunk(const BsParams &P)
     if (!BACKWARD) { o[4] = d00; o[5] = d01; o[6] = d10; o[7] = d11; }
 }
 
-// one lane per eigenvalue: string the chunks together.  Forward: a, a' (:627-628) and phi at the
-// chunk starts; backward: psi at the chunk ends.
+// one workgroup per eigenvalue: string the chunks together.  Forward: a, a' (:627-628) and phi at the
+// chunk starts; backward: psi at the chunk ends.  Three stages instead of one walk over all chunks (a chain of
+// nchunk dependent matrix-vector products, each behind a global load): (1) lane t composes the maps of its own
+// run of G = ceil(nchunk/lanes) chunks into one map {M, M'}: (p, d) -> (M p, M' p + M d); (2) lane 0 carries the
+// vector over the lanes' maps (in LDS) and leaves every run's start vector; (3) lane t walks its run again from
+// that vector and writes the vectors at its chunk boundaries.
 template <bool BACKWARD> FA_DEV void body_bs_combine(const BsParams &P)
 {
-    const int e = FA_BID * FA_BDIM + FA_TID;
-    if (e >= P.K) return;
+    FA_LDS_DECL
+    cplx *gm = (cplx *)FA_LDS_PTR;             // lanes x 8: the run's map {M[4], M'[4]}
+    cplx *gv = gm + (size_t)FA_BDIM * 8;       // lanes x 4: the run's start vector (p1, p2, d1, d2)
+    const int e = FA_BID, t = FA_TID, nl = FA_BDIM;
     const cplx lc = P.lam[e];
     const double bc = 0.5;
     const cplx *cmv = P.cm + (size_t)e * P.nchunk * 8;
+    const int G = (P.nchunk + nl - 1) / nl;
+    const int k0 = (t * G < P.nchunk) ? t * G : P.nchunk;
+    const int k1 = (k0 + G < P.nchunk) ? k0 + G : P.nchunk;
+    const cplx one = cmake(1.0, 0.0), zero = cmake(0.0, 0.0);
+    {   // stage 1
+        cplx m0 = one, m1 = zero, m2 = zero, m3 = one, d0 = zero, d1 = zero, d2 = zero, d3 = zero;
+        if (!BACKWARD) {
+            for (int k = k0; k < k1; k++) {
+                const cplx *m = cmv + (size_t)k * 8;
+                // D <- m' M + m D,  M <- m M
+                const cplx e0 = m[4] * m0 + m[5] * m2 + m[0] * d0 + m[1] * d2;
+                const cplx e1 = m[4] * m1 + m[5] * m3 + m[0] * d1 + m[1] * d3;
+                const cplx e2 = m[6] * m0 + m[7] * m2 + m[2] * d0 + m[3] * d2;
+                const cplx e3 = m[6] * m1 + m[7] * m3 + m[2] * d1 + m[3] * d3;
+                d0 = e0; d1 = e1; d2 = e2; d3 = e3;
+                const cplx f0 = m[0] * m0 + m[1] * m2, f1 = m[0] * m1 + m[1] * m3;
+                const cplx f2 = m[2] * m0 + m[3] * m2, f3 = m[2] * m1 + m[3] * m3;
+                m0 = f0; m1 = f1; m2 = f2; m3 = f3;
+            }
+        } else {
+            for (int k = k1; k-- > k0;) {
+                const cplx *m = cmv + (size_t)k * 8;
+                const cplx f0 = m[0] * m0 + m[1] * m2, f1 = m[0] * m1 + m[1] * m3;
+                const cplx f2 = m[2] * m0 + m[3] * m2, f3 = m[2] * m1 + m[3] * m3;
+                m0 = f0; m1 = f1; m2 = f2; m3 = f3;
+            }
+        }
+        cplx *o = gm + (size_t)t * 8;
+        o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3; o[4] = d0; o[5] = d1; o[6] = d2; o[7] = d3;
+    }
+    FA_SYNC();
     double s, c;
     const double tb = P.T1 + P.eps * bc;            // e^{i lam tb}
     fa_sincos(lc.x * tb, &s, &c);
     const cplx ph = cmake(c, s) * exp(-lc.y * tb);
+    if (t == 0) {   // stage 2
+        if (!BACKWARD) {
+            const double ta = P.T0 - P.eps * bc;        // e^{-i lam ta}
+            fa_sincos(-lc.x * ta, &s, &c);
+            cplx p1 = cmake(c, s) * exp(lc.y * ta), p2 = zero;
+            cplx d1 = p1 * cmake(0.0, -ta), d2 = zero;
+            for (int g = 0; g < nl; g++) {
+                cplx *v = gv + (size_t)g * 4;
+                v[0] = p1; v[1] = p2; v[2] = d1; v[3] = d2;
+                const cplx *m = gm + (size_t)g * 8;
+                const cplx n1 = m[4] * p1 + m[5] * p2 + m[0] * d1 + m[1] * d2;
+                const cplx n2 = m[6] * p1 + m[7] * p2 + m[2] * d1 + m[3] * d2;
+                d1 = n1; d2 = n2;
+                const cplx t1 = m[0] * p1 + m[1] * p2, t2 = m[2] * p1 + m[3] * p2;
+                p1 = t1; p2 = t2;
+            }
+            cplx *bnd = P.bnd + (size_t)e * (P.nchunk + 1) * 2;
+            bnd[2 * P.nchunk] = p1; bnd[2 * P.nchunk + 1] = p2;
+            const cplx av = p1 * ph;
+            P.a[e] = av;
+            P.aprime[e] = (d1 * ph + cmake(0.0, tb) * av) * (P.ups == 2 ? 0.5 : 1.0);
+        } else {
+            cplx s1 = zero, s2 = ph;
+            for (int g = nl; g-- > 0;) {
+                cplx *v = gv + (size_t)g * 4;
+                v[0] = s1; v[1] = s2;
+                const cplx *m = gm + (size_t)g * 8;
+                const cplx t1 = m[0] * s1 + m[1] * s2, t2 = m[2] * s1 + m[3] * s2;
+                s1 = t1; s2 = t2;
+            }
+            cplx *bnd = P.bndp + (size_t)e * (P.nchunk + 1) * 2;
+            bnd[0] = s1; bnd[1] = s2;
+        }
+    }
+    FA_SYNC();
+    // stage 3
+    const cplx *v = gv + (size_t)t * 4;
     if (!BACKWARD) {
-        const double ta = P.T0 - P.eps * bc;        // e^{-i lam ta}
-        fa_sincos(-lc.x * ta, &s, &c);
-        cplx p1 = cmake(c, s) * exp(lc.y * ta), p2 = cmake(0.0, 0.0);
-        cplx d1 = p1 * cmake(0.0, -ta), d2 = cmake(0.0, 0.0);
+        cplx p1 = v[0], p2 = v[1];
         cplx *bnd = P.bnd + (size_t)e * (P.nchunk + 1) * 2;
-        for (int k = 0; k < P.nchunk; k++) {
+        for (int k = k0; k < k1; k++) {
             bnd[2 * k] = p1; bnd[2 * k + 1] = p2;
             const cplx *m = cmv + (size_t)k * 8;
-            const cplx n1 = m[4] * p1 + m[5] * p2 + m[0] * d1 + m[1] * d2;
-            const cplx n2 = m[6] * p1 + m[7] * p2 + m[2] * d1 + m[3] * d2;
-            d1 = n1; d2 = n2;
             const cplx t1 = m[0] * p1 + m[1] * p2, t2 = m[2] * p1 + m[3] * p2;
             p1 = t1; p2 = t2;
         }
-        bnd[2 * P.nchunk] = p1; bnd[2 * P.nchunk + 1] = p2;
-        const cplx av = p1 * ph;
-        P.a[e] = av;
-        P.aprime[e] = (d1 * ph + cmake(0.0, tb) * av) * (P.ups == 2 ? 0.5 : 1.0);
     } else {
-        cplx s1 = cmake(0.0, 0.0), s2 = ph;
+        cplx s1 = v[0], s2 = v[1];
         cplx *bnd = P.bndp + (size_t)e * (P.nchunk + 1) * 2;
-        for (int k = P.nchunk; k-- > 0;) {
+        for (int k = k1; k-- > k0;) {
             bnd[2 * (k + 1)] = s1; bnd[2 * (k + 1) + 1] = s2;
             const cplx *m = cmv + (size_t)k * 8;
             const cplx t1 = m[0] * s1 + m[1] * s2, t2 = m[2] * s1 + m[3] * s2;
             s1 = t1; s2 = t2;
         }
-        bnd[0] = s1; bnd[1] = s2;
     }
 }
 
@@ -2522,16 +2585,30 @@ FA_DEV void body_bs_metric(const BsParams &P)
     o[1] = bval;
 }
 
+// one workgroup per eigenvalue: the chunk with the smallest metric, the first one on ties
 FA_DEV void body_bs_pick(const BsParams &P)
 {
-    const int e = FA_BID * FA_BDIM + FA_TID;
-    if (e >= P.K) return;
+    FA_LDS_DECL
+    double *lm = (double *)FA_LDS_PTR;          // lanes: best metric
+    int *li = (int *)(lm + FA_BDIM);            // lanes: its chunk
+    const int e = FA_BID, t = FA_TID, nl = FA_BDIM;
     const cplx *bv = P.best + (size_t)e * P.nchunk * 2;
     double best = 1.0e308 * 10.0;
-    cplx b = cmake(0.0, 0.0);
-    for (int c = 0; c < P.nchunk; c++)
-        if (bv[2 * c].x < best) { best = bv[2 * c].x; b = bv[2 * c + 1]; }
-    P.b[e] = b;
+    int bi = 0x7fffffff;
+    for (int c = t; c < P.nchunk; c += nl)
+        if (bv[2 * c].x < best) { best = bv[2 * c].x; bi = c; }
+    lm[t] = best;
+    li[t] = bi;
+    FA_SYNC();
+    for (int h = nl / 2; h >= 1; h >>= 1) {
+        if (t < h) {
+            const double mo = lm[t + h];
+            const int io = li[t + h];
+            if (mo < lm[t] || (mo == lm[t] && io < li[t])) { lm[t] = mo; li[t] = io; }
+        }
+        FA_SYNC();
+    }
+    if (t == 0) P.b[e] = (li[0] != 0x7fffffff) ? bv[2 * li[0] + 1] : cmake(0.0, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2544,26 +2621,43 @@ struct AberthParams {
     long long n;
     const cplx *z;       // n estimates of this sweep (read by every workgroup)
     cplx *z_out;         // the next sweep's estimates (double buffer: no workgroup reads what another one writes)
-    cplx *w;             // n Newton corrections
-    int fast;            // update kernel: single-precision Aberth sum (sweeps far from convergence)
+    int fast;            // sum kernel: single-precision Aberth sum (sweeps far from convergence)
     unsigned long long *maxcorr;   // bits of max |corr|/|z| of the sweep
+    // Both O(n^2) kernels are cut into S segments (second grid dimension) so that a polynomial of a few 10^4
+    // roots fills the chip: segment s of the Newton kernel evaluates the powers [s*L, (s+1)*L) of every estimate,
+    // segment s of the sum kernel adds the terms of the estimates [s*J, (s+1)*J); the apply kernel joins them.
+    int S;
+    long long L;         // powers per Newton segment (a multiple of the chain count)
+    long long J;         // estimates per segment of the Aberth sum
+    cplx *pp, *pd;       // S*na: value and derivative of segment s's polynomial (in x, powers 0 .. L-1) at estimate idx[i]
+    double *pe;          // S*na: its error scale sum |c_j| |x|^j
+    cplx *ps;            // S*na: partial Aberth sums
+    int *hit;            // n: estimate coincides with another one
+    // Only the estimates that still move are worked on: an estimate whose Newton correction is zero (|p| at the
+    // level of its evaluation error) stays where it is, so p need not be evaluated there again.  idx lists the
+    // na estimates of this sweep (lane i of every kernel works on estimate idx[i]; the segment arrays above are
+    // indexed [s*na + i]); the apply kernel appends those that moved to idx_out and counts them in *cnt.
+    const int *idx;
+    int *idx_out;
+    int *cnt;
+    long long na;
 };
 
 // p(x) = sum_r x^r P_r(x^NCH): NCH independent Horner chains (plus their derivatives and the |coefficient| chains
-// of the error scale) per lane -- the kernel runs at less than one wave per SIMD (one lane per estimate), so the
-// instruction-level parallelism of the chains is what keeps the pipeline busy -- with the coefficients staged
-// through LDS in tiles that the workgroup loads together.  asc(k) is the coefficient of x^k: x = z reads
-// coef[n-k], x = 1/z (|z| > 1) reads coef[k].
+// of the error scale) per lane, with the coefficients staged through LDS in tiles that the workgroup loads
+// together.  asc(k) is the coefficient of x^k: x = z reads coef[n-k], x = 1/z (|z| > 1) reads coef[k].
+// blockIdx.y = segment of the coefficient range (AberthParams).
 template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
 {
     constexpr int NCH = 8;
     FA_LDS_DECL
     cplx *tile = (cplx *)FA_LDS_PTR;
     double *tabs = (double *)(tile + 2 * TILE);   // |coefficient| of the same tile, both orientations
-    const long long k = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long li = (long long)FA_BID * FA_BDIM + FA_TID;
     const long long n = P.n;
-    const bool act = k < n;
-    const cplx z = act ? P.z[k] : cmake(0.5, 0.0);
+    const long long base = (long long)FA_BID_Y * P.L;   // lowest power of this segment
+    const bool act = li < P.na;
+    const cplx z = act ? P.z[P.idx[li]] : cmake(0.5, 0.0);
     const bool inside = cnorm2(z) <= 1.0;
     const cplx x = inside ? z : c_div(cmake(1.0, 0.0), z);
     cplx xp[NCH];               // x^0 .. x^(NCH-1)
@@ -2579,11 +2673,12 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
     double ec[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) { pc[c] = cmake(0.0, 0.0); dc[c] = cmake(0.0, 0.0); ec[c] = 0.0; }
-    // powers run from the top block (m = Mtop) down to m = 0; block m holds powers NCH*m .. NCH*m + NCH-1
-    const long long Mtop = n / NCH;
+    // local powers run from the top block (m = Mtop) down to m = 0; block m holds powers NCH*m .. NCH*m + NCH-1
+    const long long Mtop = P.L / NCH - 1;
     for (long long mhi = Mtop; mhi >= 0; mhi -= TILE / NCH) {
         const long long mlo = (mhi - TILE / NCH + 1 > 0) ? mhi - TILE / NCH + 1 : 0;
-        const long long kbase = NCH * mlo;            // lowest power held by this tile
+        const long long kbase = base + NCH * mlo;     // lowest (global) power held by this tile
+        if (kbase > n) continue;                      // the whole tile lies above the leading coefficient (uniform)
         FA_SYNC();
         for (int t = FA_TID; t < TILE; t += FA_BDIM) {
             const long long kk = kbase + t;
@@ -2620,23 +2715,32 @@ template <int TILE> FA_DEV void body_aberth_newton(const AberthParams &P)
         escale = fma(axp, ec[c], escale);
     }
     dp = dp + (xp[NCH - 1] * dsum) * (double)NCH;
-    // |p(x)| at the level of its own evaluation error (running error bound of Horner's scheme, statistical
-    // sqrt(n) growth): the estimate is a root to working accuracy and is left alone -- without this, roots of
-    // an ill-conditioned polynomial keep receiving corrections of the size of the noise and never "converge"
-    const double noise = 2.220446049250313e-16 * (2.0 * sqrt((double)n) + 2.0) * escale;
-    const cplx x2 = xp[2];
-    cplx wv;
-    if (cnorm2(p) <= noise * noise) {
-        wv = cmake(0.0, 0.0);
-    } else if (inside) {
-        wv = c_div(p, dp);
-    } else {
-        // p(z) = z^n q(y), y = 1/z:  p'/p = n/z - y^2 q'(y)/q(y)
-        const cplx t = x * (double)n - x2 * c_div(dp, p);
-        wv = c_div(cmake(1.0, 0.0), t);
+    const long long o = (long long)FA_BID_Y * P.na + li;
+    P.pp[o] = p;
+    P.pd[o] = dp;
+    P.pe[o] = escale;
+}
+
+// x^e, e >= 0, by repeated squaring (|x| <= 1: underflow to zero is the right answer)
+FA_DEV cplx c_powi(cplx x, long long e)
+{
+    cplx r = cmake(1.0, 0.0);
+    while (e > 0) {
+        if (e & 1) r = r * x;
+        x = x * x;
+        e >>= 1;
     }
-    if (!(wv.x == wv.x) || !(wv.y == wv.y) || fabs(wv.x) > 1.0e300 || fabs(wv.y) > 1.0e300) wv = cmake(0.0, 0.0);
-    P.w[k] = wv;
+    return r;
+}
+
+// 1/x for the Aberth sums: hardware reciprocal + two Newton steps (no scaling / fix-up of the IEEE division:
+// the arguments are squared distances of estimates, far from the ends of the exponent range)
+FA_DEV double aberth_rcp(double x)
+{
+    double r = fa_rcp_approx(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
 }
 
 // One term 1/(zk - zj) = conj(d)/|d|^2 of the Aberth sum, branch-free: the own term counts as 1/(1 + 0i) (taken
@@ -2651,33 +2755,37 @@ FA_DEV cplx aberth_term(cplx zk, cplx zj, bool own, bool &hit)
     const bool zero = (n2 == 0.0);
     hit = hit || zero;
     n2 = zero ? 1.0 : n2;
-    const double inv = 1.0 / n2;
+    const double inv = aberth_rcp(n2);
     return cmake(d.x * inv, -d.y * inv);
 }
-template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
+// Partial Aberth sums: blockIdx.y = segment of the estimates z_j, lane = estimate k.
+template <int TILE> FA_DEV void body_aberth_sum(const AberthParams &P)
 {
     FA_LDS_DECL
     cplx *tile = (cplx *)FA_LDS_PTR;
-    const long long k = (long long)FA_BID * FA_BDIM + FA_TID;
-    const bool act = k < P.n;
+    const long long li = (long long)FA_BID * FA_BDIM + FA_TID;
+    const bool act = li < P.na;
+    const long long k = act ? (long long)P.idx[li] : -1;
     const cplx zk = act ? P.z[k] : cmake(0.0, 0.0);
+    const long long jlo = (long long)FA_BID_Y * P.J;
+    const long long jhi = (jlo + P.J < P.n) ? jlo + P.J : P.n;
     cplx s = cmake(0.0, 0.0);
     bool hit = false;   // this estimate coincides with another one
     if (P.fast) {
         // far from convergence (corrections of 1e-3 and more) the repulsion sum only steers the estimates apart:
-        // single precision is plenty, and it runs at several times the rate of the double-precision divisions
+        // single precision is plenty, and it runs at several times the rate of the double-precision reciprocals
         float sx = 0.f, sy = 0.f, tx = 0.f, ty = 0.f;
         const float zx = (float)zk.x, zy = (float)zk.y;
         float *tf = (float *)tile;
-        for (long long j0 = 0; j0 < P.n; j0 += TILE) {
+        for (long long j0 = jlo; j0 < jhi; j0 += TILE) {
             FA_SYNC();
-            if (j0 + FA_TID < P.n) {
+            if (j0 + FA_TID < jhi) {
                 const cplx zj = P.z[j0 + FA_TID];
                 tf[2 * FA_TID] = (float)zj.x;
                 tf[2 * FA_TID + 1] = (float)zj.y;
             }
             FA_SYNC();
-            const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
+            const int lim = (int)((jhi - j0 < TILE) ? jhi - j0 : TILE);
             if (act) {
                 int j = 0;
                 for (; j + 1 < lim; j += 2) {
@@ -2685,25 +2793,25 @@ template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
                     float bx = zx - tf[2 * j + 2], by = zy - tf[2 * j + 3];
                     float na = ax * ax + ay * ay, nb = bx * bx + by * by;
                     // own term and exact coincidences contribute nothing (the double-precision sweeps separate them)
-                    const float ia = (na > 0.f) ? 1.0f / na : 0.f, ib = (nb > 0.f) ? 1.0f / nb : 0.f;
+                    const float ia = (na > 0.f) ? fa_rcp_approx_f32(na) : 0.f, ib = (nb > 0.f) ? fa_rcp_approx_f32(nb) : 0.f;
                     sx += ax * ia; sy -= ay * ia;
                     tx += bx * ib; ty -= by * ib;
                 }
                 if (j < lim) {
                     const float ax = zx - tf[2 * j], ay = zy - tf[2 * j + 1];
                     const float na = ax * ax + ay * ay;
-                    const float ia = (na > 0.f) ? 1.0f / na : 0.f;
+                    const float ia = (na > 0.f) ? fa_rcp_approx_f32(na) : 0.f;
                     sx += ax * ia; sy -= ay * ia;
                 }
             }
         }
         s = cmake((double)sx + (double)tx, (double)sy + (double)ty);
     } else {
-        for (long long j0 = 0; j0 < P.n; j0 += TILE) {
+        for (long long j0 = jlo; j0 < jhi; j0 += TILE) {
             FA_SYNC();
-            if (j0 + FA_TID < P.n) tile[FA_TID] = P.z[j0 + FA_TID];
+            if (j0 + FA_TID < jhi) tile[FA_TID] = P.z[j0 + FA_TID];
             FA_SYNC();
-            const int lim = (int)((P.n - j0 < TILE) ? P.n - j0 : TILE);
+            const int lim = (int)((jhi - j0 < TILE) ? jhi - j0 : TILE);
             if (act) {
                 cplx s1 = cmake(0.0, 0.0);
                 int j = 0;
@@ -2715,12 +2823,61 @@ template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
                 s = s + s1;
             }
         }
-        s = s - cmake(1.0, 0.0);   // the own term was counted as 1/(1 + 0i)
+        if (k >= jlo && k < jhi) s = s - cmake(1.0, 0.0);   // the own term was counted as 1/(1 + 0i)
     }
-    FA_SYNC();
-    double rel = 0.0;
     if (act) {
-        const cplx w = P.w[k];
+        P.ps[(long long)FA_BID_Y * P.na + li] = s;
+        if (hit) P.hit[k] = 1;
+    }
+}
+
+// Joins the segments: p(z), p'(z) and the error scale from the segment polynomials (Horner in x^L), the Newton
+// correction w = p/p', the Aberth sum, and the new estimate z - w/(1 - w*sum).
+FA_DEV void body_aberth_apply(const AberthParams &P)
+{
+    const long long li = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long n = P.n;
+    const bool act = li < P.na;
+    double rel = 0.0;
+    bool moved = false;
+    long long k = 0;
+    if (act) {
+        k = P.idx[li];
+        const cplx zk = P.z[k];
+        const bool inside = cnorm2(zk) <= 1.0;
+        const cplx x = inside ? zk : c_div(cmake(1.0, 0.0), zk);
+        const cplx xL1 = c_powi(x, P.L - 1), xL = xL1 * x;
+        const double axL = sqrt(cnorm2(xL));
+        // Q(y) = sum_s p_s y^s at y = x^L:  p = Q,  p' = sum_s y^s p_s' + L x^(L-1) Q'(y)
+        cplx q = cmake(0.0, 0.0), dq = cmake(0.0, 0.0), d = cmake(0.0, 0.0), s = cmake(0.0, 0.0);
+        double escale = 0.0;
+        for (int g = P.S - 1; g >= 0; g--) {
+            const long long o = (long long)g * P.na + li;
+            dq = dq * xL + q;
+            q = q * xL + P.pp[o];
+            d = d * xL + P.pd[o];
+            escale = fma(escale, axL, P.pe[o]);
+            s = s + P.ps[o];
+        }
+        const cplx p = q;
+        const cplx dp = d + (xL1 * dq) * (double)P.L;
+        // |p(x)| at the level of its own evaluation error (running error bound of Horner's scheme, statistical
+        // sqrt(n) growth): the estimate is a root to working accuracy and is left alone -- without this, roots of
+        // an ill-conditioned polynomial keep receiving corrections of the size of the noise and never "converge"
+        const double noise = 2.220446049250313e-16 * (2.0 * sqrt((double)n) + 2.0) * escale;
+        cplx w;
+        if (cnorm2(p) <= noise * noise) {
+            w = cmake(0.0, 0.0);
+        } else if (inside) {
+            w = c_div(p, dp);
+        } else {
+            // p(z) = z^n q(y), y = 1/z:  p'/p = n/z - y^2 q'(y)/q(y)
+            const cplx t = x * (double)n - (x * x) * c_div(dp, p);
+            w = c_div(cmake(1.0, 0.0), t);
+        }
+        if (!(w.x == w.x) || !(w.y == w.y) || fabs(w.x) > 1.0e300 || fabs(w.y) > 1.0e300) w = cmake(0.0, 0.0);
+        const bool hit = P.hit[k] != 0;
+        P.hit[k] = 0;
         cplx corr = c_div(w, cmake(1.0, 0.0) - w * s);
         const double az0 = sqrt(cnorm2(zk));
         if (hit) {   // coincident estimates: separate them (different steps for different k)
@@ -2734,9 +2891,12 @@ template <int TILE> FA_DEV void body_aberth_update(const AberthParams &P)
             corr = cmake(h * (1.0 + (double)(k & 3)), -h * (1.0 + (double)((k >> 2) & 3)));
         }
         const cplx zn = zk - corr;
-        P.z_out[k] = zn;
+        P.z_out[k] = zn;   // an estimate that stays writes its value into the other buffer too: both agree from now on
+        moved = (corr.x != 0.0 || corr.y != 0.0);
         const double az = sqrt(cnorm2(zn));
         rel = sqrt(cnorm2(corr)) / (az > 1.0e-300 ? az : 1.0e-300);
     }
+    const int slot = fa_wave_append_slot(P.cnt, moved);
+    if (moved) P.idx_out[slot] = (int)k;
     fa_wave_atomic_max_f64bits(P.maxcorr, rel);
 }
