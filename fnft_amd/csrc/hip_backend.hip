@@ -644,7 +644,7 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
     NftDiscSpec<HipBackend> ds(be);
     NftDiscSpec<HipBackend>::Prepared P;
     // any 2SPLIT scheme: upsampling factor 1, the slow scatterer is BO (src/fnft_nsev.c:675-680)
-    int rc = ds.prepare(D, (const std::complex<double> *)q, T, D, (int)fnft_nse_discretization_2SPLIT4B, P);
+    int rc = ds.prepare(D, (const std::complex<double> *)q, T, D, (int)fnft_nse_discretization_2SPLIT4B, P, false);
     if (rc == NFT_SUCCESS)
         rc = ds.scatter(P, K, (const std::complex<double> *)bound_states, (std::complex<double> *)a_vals,
                         (std::complex<double> *)aprime_vals, (std::complex<double> *)b, skip_b_flag != 0);

@@ -85,7 +85,10 @@ public:
     }
 
     // fnft__nse_discretization_preprocess_signal(D, q, eps_t, kappa = +1, &Dsub, ...), :386-656
-    int prepare(size_t D, const cd *q, const double T[2], size_t Dsub_wish, int nse_disc, Prepared &P)
+    // need_tree = false: the signal is only handed to the slow scatterer (Newton refinement, norming constants);
+    // without resampling (2SPLIT*) that needs the samples on the device and no plan at all.
+    int prepare(size_t D, const cd *q, const double T[2], size_t Dsub_wish, int nse_disc, Prepared &P,
+                bool need_tree = true)
     {
         const int akns = nft_nse_to_akns(nse_disc);
         if (akns < 0) return NFT_EC_INVALID_ARGUMENT;
@@ -111,9 +114,18 @@ public:
             src = hq.data();
             Din = Dsub;
         }
+        int rc = NFT_SUCCESS;
+        if (!need_tree && P.ups == 1) {
+            P.d_in = (cplx *)be.alloc(Din * sizeof(cplx));
+            if (!P.d_in) return NFT_EC_NOMEM;
+            be.h2d(P.d_in, src, Din * sizeof(cplx));
+            P.d_qpre = P.d_in;
+            P.h_qpre.assign(src, src + Din);
+            return be.sync();
+        }
         P.pl.reset(new NftPlan<BE>(be, P.Deff, 0, 1, akns, P.deg0));
         P.pl->set_front(Din, P.ups == 1 ? 1 : nskip, P.ups);
-        int rc = P.pl->init();
+        rc = P.pl->init();
         if (rc != NFT_SUCCESS) return rc;
         P.d_in = (cplx *)be.alloc(Din * sizeof(cplx));
         if (!P.d_in) return NFT_EC_NOMEM;
@@ -439,7 +451,7 @@ public:
         NftDsOpts ob = o;
         NftDsClock clk;
         if (o.richardson && o.dstype == 1) ob.dstype = 2;   // residues need norming constants too, :248-258
-        int rc = prepare(D, q, T, D, o.nse_disc, full);
+        int rc = prepare(D, q, T, D, o.nse_disc, full, o.bsloc == 0);
         clk.lap("prepare(full)");
         if (rc == NFT_SUCCESS) {
             if (o.bsloc == 2) {   // SUBSAMPLE_AND_REFINE, :276-304
@@ -473,7 +485,7 @@ public:
         if (rc == NFT_SUCCESS && o.richardson && !bs.empty()) {
             Prepared half;
             std::vector<cd> bs_s(bs), nc_s, ap_s;
-            rc = prepare(D, q, T, D / 2, o.nse_disc, half);
+            rc = prepare(D, q, T, D / 2, o.nse_disc, half, false);
             if (rc == NFT_SUCCESS) rc = base(half, ob, 1, bs_s, normconsts_or_residues ? &nc_s : nullptr, &ap_s);
             if (rc == NFT_SUCCESS && !bs_s.empty()) {
                 const double eps_t = (T[1] - T[0]) / (double)(D - 1);

@@ -228,14 +228,18 @@ template <int N1> struct KColBridge2 {   // spectral doubling: same tiling as th
 #ifndef FA_MID_R
 #define FA_MID_R 8   // points per lane of the row kernel (4: 512 lanes per row, 4 waves per SIMD)
 #endif
+#ifndef FA_MID4_R
+#define FA_MID4_R 4   // points per lane of the general 4-entry row kernel: 512 lanes per row, 232 VGPRs, 2 waves per SIMD
+                     // (8: 256 lanes, 394-410 VGPRs, 1 wave per SIMD; cfg 5 row kernel 390 -> 345 us)
+#endif
 template <int NE> struct KMid {
     using Params = BigLevel;
-    static constexpr int R = FA_MID_R;
+    static constexpr int R = (NE == 4) ? FA_MID4_R : FA_MID_R;
     static constexpr int THREADS = kRowTree / R;
 #ifndef FA_MID4_WAVES
 #define FA_MID4_WAVES 1   // general 4-entry form: 1 = 394 VGPRs, no spills (2: 186 spilled); cfg 5 split levels 6.35 -> 6.17 ms
 #endif
-    static constexpr int MIN_WAVES = (R == 4) ? 4 : (NE == 4 ? FA_MID4_WAVES : 2);
+    static constexpr int MIN_WAVES = (NE == 4) ? (R == 4 ? 2 : FA_MID4_WAVES) : (R == 4 ? 4 : 2);
     static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_mid<kRowTree, R, NE>(p); }
 };

@@ -1874,13 +1874,10 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
 // add its exponent (intermediate split levels are finalized by their consumers, TreeLevel::in_pending)
 FA_DEV void body_finalize_scales(const TreeLevel &L)
 {
-    const long long P = (long long)FA_BID * FA_BDIM + FA_TID;
-    if (P >= L.n_in / 2) return;
-    unsigned hi = 0u;
-    for (int sl = 0; sl < kMax2Slots; sl++) {
-        const unsigned x = L.max2_out[(size_t)P * kMax2Slots + sl];
-        hi = x > hi ? x : hi;
-    }
+    // one wave per output matrix: the kMax2Slots maxima are read by one lane each
+    const long long P = FA_BID;
+    const unsigned hi = fa_slots_max_u32(L.max2_out + (size_t)P * kMax2Slots);
+    if (FA_TID != 0) return;
     const int a = exponent_of_max2(hi);
     L.scale_out[P] = pow2i(-a);
     L.wexp_out[P] = L.wexp_out[P] + a;

@@ -223,6 +223,7 @@ public:
         {   // split levels hold at most n0*deg0/2048 matrices, kMax2Slots slots each
             const size_t nm = n0 * (size_t)deg0 / 32 + 4 * (size_t)kMax2Slots;
             ok = ok && alloc(max2[0], nm) && alloc(max2[1], nm) && alloc(status, 4);
+            if (ok) be.memset0(status, 4 * sizeof(int));
         }
         {   // scratch of the split transforms: 4*n_in polynomials of N forward, 4*n_out inverse,
             // maximised over the levels that use them (N can exceed 2d when d is not 2^k)
@@ -321,7 +322,6 @@ public:
             Tsub[1] = T[1];
             return run_coeffs(d_q, kdv ? rneg : nullptr, eps_in, kappa);
         }
-        be.memset0(status, 4 * sizeof(int));   // the resampler below may set the "not band-limited" bit
         const size_t Dsub = D / 2;
         Tsub[0] = T[0];
         Tsub[1] = T[0] + (double)((Dsub - 1) * nskip) * eps_in;
@@ -368,7 +368,7 @@ public:
     // ---- level 0 from samples (fnft__akns_fscatter.c:116-917) --------------------------------
     int run_coeffs(const void *d_q, const void *d_r, double eps_t, int kappa, bool clear_status = true)
     {
-        if (clear_status) be.memset0(status, 4 * sizeof(int));
+        (void)clear_status;   // the status word is cleared by whoever reads it (read_status), not per transform
         CoeffParams p;
         p.q = (const cplx *)d_q;
         p.r = (const cplx *)d_r;
@@ -450,7 +450,6 @@ public:
         be.h2d(tail[0], ht.data(), ht.size() * sizeof(cplx));
         be.h2d(scale[0], hs.data(), hs.size() * sizeof(double));
         be.memset0(wexp[0], n0 * sizeof(int));
-        be.memset0(status, 4 * sizeof(int));
         cur = 0;
         ne = 4;
         start_n = n0;
@@ -560,7 +559,7 @@ public:
                 y_from_bridge = ok && next_split;
                 // the consumer of the next level finalizes this one; the last level needs a kernel
                 const bool last_level = (n / 2 / batch <= 1);
-                if (ok && last_level) be.template run<KFinalizeScales>((int)((n / 2 + 63) / 64), 1, L);
+                if (ok && last_level) be.template run<KFinalizeScales>((int)(n / 2), 1, L);   // one wave per matrix
                 in_pending = !last_level;
                 mcur ^= 1;
             }
@@ -619,7 +618,6 @@ public:
         if (!wuser && !alloc(wuser, batch)) return NFT_EC_NOMEM;
         std::vector<int> hw(batch, W);
         be.h2d(wuser, hw.data(), batch * sizeof(int));
-        be.memset0(status, 4 * sizeof(int));
         return run_contspec_impl(d_contspec, cs, (const cplx *)d_tm, 1);
     }
 
@@ -850,6 +848,8 @@ public:
         be.d2h(h, status, sizeof(h));
         const int rc = be.sync();
         if (rc != NFT_SUCCESS) return rc;
+        // sticky bits of every transform since the last read; cleared here (off the transforms' critical path)
+        be.memset0(status, 4 * sizeof(int));
         last_warn = (h[0] & 4) ? 1 : 0;            // fnft__misc.c:371-381: not an error
         if (h[0] & 1) return -NFT_EC_OTHER;        // fnft__akns_fscatter.c:122-126 via CHECK_RETCODE
         if (h[0] & 2) return -NFT_EC_DIV_BY_ZERO;  // fnft_nsev.c:850-853 via CHECK_RETCODE
