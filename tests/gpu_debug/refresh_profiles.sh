@@ -12,7 +12,7 @@ python bench.py --workload cfg3 > gpurun_out/$R/bench_cfg3.json 2>> gpurun_out/$
 python bench.py --workload cfg4 > gpurun_out/$R/bench_cfg4.json 2>> gpurun_out/$R/bench.err
 python bench.py --workload cfg5 > gpurun_out/$R/bench_cfg5.json 2>> gpurun_out/$R/bench.err
 echo workloads done
-rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof -o $R --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/$R/bench_under_rocprof.json 2> gpurun_out/$R/rocprof.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof -o $R --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined > gpurun_out/$R/bench_under_rocprof.json 2> gpurun_out/$R/rocprof.err
 echo rocprof done
 bash tests/gpu_debug/pmc_passes.sh ${R}_cfg2 > gpurun_out/$R/pmc_cfg2.log 2>&1
 echo pmc cfg2 done
