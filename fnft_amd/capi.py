@@ -65,6 +65,23 @@ class NsevOpts(C.Structure):
     ]
 
 
+class NsevInverseOpts(C.Structure):
+    """fnft_nsev_inverse_opts_t, include/fnft_nsev_inverse.h:155-162 (same field order = same ABI)."""
+    _fields_ = [
+        ("discretization", C.c_int),
+        ("contspec_type", C.c_int),
+        ("contspec_inversion_method", C.c_int),
+        ("discspec_type", C.c_int),
+        ("max_iter", C.c_size_t),
+        ("oversampling_factor", C.c_size_t),
+    ]
+
+
+INV_CSTYPE = {"REFLECTION_COEFFICIENT": 0, "B_OF_XI": 1, "B_OF_TAU": 2}
+INV_DSTYPE = {"NORMING_CONSTANTS": 0, "RESIDUES": 1}
+INV_CSMETHOD = {"DEFAULT": 0, "TFMATRIX_CONTAINS_REFL_COEFF": 1, "TFMATRIX_CONTAINS_AB_FROM_ITER": 2,
+                "USE_SEED_POTENTIAL_INSTEAD": 3}
+
 PRINTF_T = C.CFUNCTYPE(C.c_int32, C.c_char_p)  # variadic in C; used only to silence output
 
 EXPORTED = [
@@ -81,6 +98,7 @@ EXPORTED = [
     "fnft__nse_scatter_bound_states", "fnft__poly_fmult_numel", "fnft__poly_fmult", "fnft__poly_fmult_two_polys_len",
     "fnft__poly_fmult_two_polys", "fnft__poly_fmult_two_polys2x2", "fnft__nse_finvscatter",
     "fnft_amd_plan_last_warnings", "fnft_amd_discspec_stage_ms",
+    "fnft_nsev_inverse", "fnft_nsev_inverse_default_opts", "fnft_nsev_inverse_XI", "fnft__poly_specfact",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -189,6 +207,13 @@ def load(path=None):
     L.fnft__poly_fmult_two_polys.argtypes = [sz, vp, vp, vp, vp, vp, vp, vp, vp, sz]
     L.fnft__poly_fmult_two_polys2x2.restype = i32
     L.fnft__poly_fmult_two_polys2x2.argtypes = [sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, sz]
+    L.fnft_nsev_inverse_default_opts.restype = NsevInverseOpts
+    L.fnft_nsev_inverse_XI.restype = i32
+    L.fnft_nsev_inverse_XI.argtypes = [sz, vp, sz, vp, C.c_int]
+    L.fnft_nsev_inverse.restype = i32
+    L.fnft_nsev_inverse.argtypes = [sz, vp, vp, sz, vp, vp, sz, vp, vp, i32, vp]
+    L.fnft__poly_specfact.restype = i32
+    L.fnft__poly_specfact.argtypes = [sz, vp, vp, sz, i32]
     L.fnft__nse_finvscatter.restype = i32
     L.fnft__nse_finvscatter.argtypes = [sz, vp, vp, dbl, i32, C.c_int]
     L.fnft_amd_discspec_stage_ms.restype = dbl
@@ -366,6 +391,55 @@ def nse_finvscatter(tm, eps_t, kappa, discretization):
     d = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
     rc = L.fnft__nse_finvscatter(deg, _ptr(tm), _ptr(q), float(eps_t), int(kappa), d)
     return int(rc), q[:deg]
+
+
+def nsev_inverse_XI(D, T, M, discretization="2SPLIT2A"):
+    """fnft_nsev_inverse_XI: (rc, [XI0, XI1])."""
+    L = load()
+    Tn = np.ascontiguousarray(T, np.float64)
+    XI = np.zeros(2, np.float64)
+    d = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    rc = L.fnft_nsev_inverse_XI(int(D), _ptr(Tn), int(M), _ptr(XI), d)
+    return int(rc), [float(XI[0]), float(XI[1])]
+
+
+def fnft_nsev_inverse(M, contspec, XI, bound_states, normconsts_or_residues, D, T, kappa, opts=None, q_seed=None):
+    """fnft_nsev_inverse() through the C ABI with host (numpy) buffers: (rc, q[D]).  opts: dict with the names of the
+    reference's option fields (strings for the enums).  contspec, if a complex128 array, is modified in place as the
+    reference modifies its argument; q_seed: the seed potential of USE_SEED_POTENTIAL_INSTEAD."""
+    L = load()
+    o = L.fnft_nsev_inverse_default_opts()
+    for k, v in (opts or {}).items():
+        if k == "discretization":
+            v = NSE_DISC[v] if isinstance(v, str) else int(v)
+        elif k == "contspec_type":
+            v = INV_CSTYPE[v] if isinstance(v, str) else int(v)
+        elif k == "contspec_inversion_method":
+            v = INV_CSMETHOD[v] if isinstance(v, str) else int(v)
+        elif k == "discspec_type":
+            v = INV_DSTYPE[v] if isinstance(v, str) else int(v)
+        setattr(o, k, v)
+    cs = None if contspec is None else (contspec if (isinstance(contspec, np.ndarray) and contspec.dtype == np.complex128
+                                                     and contspec.flags.c_contiguous) else _c128(contspec))
+    Tn = None if T is None else np.ascontiguousarray(T, np.float64)
+    XIn = None if XI is None else np.ascontiguousarray(XI, np.float64)
+    bs = None if bound_states is None else _c128(bound_states)
+    nc = None if normconsts_or_residues is None else _c128(normconsts_or_residues)
+    K = 0 if bs is None else bs.size
+    q = np.zeros(max(int(D), 1), np.complex128) if q_seed is None else _c128(q_seed).copy()
+    rc = L.fnft_nsev_inverse(int(M), None if cs is None else _ptr(cs), None if XIn is None else _ptr(XIn), K,
+                             None if bs is None else _ptr(bs), None if nc is None else _ptr(nc), int(D), _ptr(q),
+                             None if Tn is None else _ptr(Tn), int(kappa), C.byref(o))
+    return int(rc), q[:int(D)]
+
+
+def poly_specfact(poly, oversampling_factor, kappa):
+    """fnft__poly_specfact: poly [deg+1] -> (rc, result[deg+1])."""
+    L = load()
+    poly = _c128(poly)
+    out = np.zeros(poly.size, np.complex128)
+    rc = L.fnft__poly_specfact(poly.size - 1, _ptr(poly), _ptr(out), int(oversampling_factor), int(kappa))
+    return int(rc), out
 
 
 def misc_resample(q, eps_t, delta):

@@ -7,6 +7,7 @@
 
 #include "hip_be.h"
 #include "nft_inverse.h"
+#include "nft_nsev_inverse.h"
 #include "../../include/fnft_amd.h"
 
 thread_local std::string g_last_error;
@@ -564,6 +565,86 @@ FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer
     NftLayerPeeling<InvProduct> lp(prod, eps_t, (int)kappa, modal ? 1 : 0);
     lp.peel(deg, transfer_matrix, deg + 1, nullptr, 0, q);
     return lp.rc;
+}
+
+// ---- fnft_nsev_inverse (driver: fnft_nsev_inverse_host.c) ---------------------------------------------------------
+// include/private/fnft__poly_specfact.h (src/private/fnft__poly_specfact.c:25-140)
+FNFT_INT fnft__poly_specfact(const FNFT_UINT deg, FNFT_COMPLEX const *const poly, FNFT_COMPLEX *const result,
+                             const FNFT_UINT oversampling_factor, const FNFT_INT kappa)
+{
+    if (deg == 0 || !poly || !result || oversampling_factor == 0) return FNFT_EC_INVALID_ARGUMENT;   // :31-38
+    if (kappa != 0 && kappa != 1 && kappa != -1) return FNFT_EC_INVALID_ARGUMENT;                     // :105-107
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    NftInverseDev<HipBackend> inv(be);
+    int warn = 0;
+    const int rc = inv.specfact_host(deg, poly, result, oversampling_factor, (int)kappa, &warn);
+    if (be.failed) return FNFT_EC_OTHER;
+    if (rc == FNFT_SUCCESS && warn) fnft_amd__warn("Ill-posed spectral factorization problem.", "fnft__poly_specfact", __LINE__);
+    return rc;
+}
+
+extern "C" FNFT_INT fnft_amd__inverse_transfer_matrix(FNFT_UINT M, FNFT_COMPLEX *contspec, const FNFT_REAL *XI, FNFT_UINT K,
+                                                      const FNFT_COMPLEX *bound_states, FNFT_UINT D, const FNFT_REAL *T,
+                                                      FNFT_UINT deg, FNFT_COMPLEX *tm, FNFT_INT kappa, int cstype,
+                                                      int method, FNFT_UINT max_iter, FNFT_UINT oversampling,
+                                                      FNFT_REAL phase_factor, int *warn_specfact, int *warn_maxiter)
+{
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    NftInverseDev<HipBackend> inv(be);
+    const int rc = inv.transfer_matrix(M, contspec, XI, K, bound_states, D, T, deg, tm, (int)kappa, cstype, method,
+                                       max_iter, oversampling, phase_factor, warn_specfact, warn_maxiter);
+    if (be.failed) return FNFT_EC_OTHER;
+    return rc;
+}
+
+// src/fnft_nsev_inverse.c:680-903: host bookkeeping (sorting, residues -> norming constants), device Darboux steps
+extern "C" FNFT_INT fnft_amd__inverse_add_discrete(FNFT_UINT K, const FNFT_COMPLEX *bound_states,
+                                                   const FNFT_COMPLEX *normconsts_or_residues, FNFT_UINT D,
+                                                   FNFT_COMPLEX *q, const FNFT_REAL *T, int contspec_flag, int residues,
+                                                   int seed_method)
+{
+    typedef std::complex<double> cd;
+    if (K == 0 || !bound_states || !normconsts_or_residues) return FNFT_EC_INVALID_ARGUMENT;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    std::vector<cd> bs(bound_states, bound_states + K), nc(normconsts_or_residues, normconsts_or_residues + K);
+    for (size_t i = 0; i < K; i++)            // descending imaginary part, the reference's exchange sort (:742-754)
+        for (size_t j = i + 1; j < K; j++)
+            if (bs[i].imag() < bs[j].imag()) { std::swap(bs[i], bs[j]); std::swap(nc[i], nc[j]); }
+    for (size_t i = 0; i + 1 < K; i++)
+        if (bs[i + 1] == bs[i]) return FNFT_EC_SANITY_CHECK_FAILED;   // :756-761
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    int rc = FNFT_SUCCESS;
+    if (residues) {                                                    // :771-795
+        std::vector<cd> acs(K, cd(1.0, 0.0)), ap(K), bdummy(K);
+        if (contspec_flag) {
+            // the non-solitonic part of the potential contributes to the residues: a(lambda_k) of the seed, BO scheme
+            NftDiscSpec<HipBackend> ds(be);
+            NftDiscSpec<HipBackend>::Prepared P;
+            rc = ds.prepare(D, q, T, D, (int)fnft_nse_discretization_2SPLIT4B, P, false);
+            if (rc == FNFT_SUCCESS) rc = ds.scatter(P, K, bs.data(), acs.data(), ap.data(), bdummy.data(), true);
+            ds.release(P);
+            if (rc != FNFT_SUCCESS || be.failed) return be.failed ? FNFT_EC_OTHER : rc;
+        }
+        for (size_t i = 0; i < K; i++) {
+            cd tmp = acs[i];
+            for (size_t j = 0; j < K; j++)
+                if (j != i) tmp = tmp * (bs[i] - bs[j]) / (bs[i] - std::conj(bs[j]));
+            nc[i] = (nc[i] / cd(0.0, 2.0 * bs[i].imag())) * tmp;
+        }
+    }
+    int mode;
+    if (contspec_flag == 0 && !seed_method) mode = 0;
+    else if ((contspec_flag == 0 && seed_method) || (contspec_flag == 1 && !seed_method)) mode = 1;
+    else return FNFT_EC_INVALID_ARGUMENT;                              // :890-891
+    NftInverseDev<HipBackend> inv(be);
+    rc = inv.add_discrete(K, bs.data(), nc.data(), D, q, T, mode);
+    if (be.failed) return FNFT_EC_OTHER;
+    return rc;
 }
 
 FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const double *A,

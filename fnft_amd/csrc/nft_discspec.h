@@ -155,6 +155,7 @@ public:
         B.q = P.d_qpre;
         B.D = (long long)P.Deff;
         B.ups = P.ups;
+        B.lscale = (P.ups == 2) ? 0.5 : 1.0;
         B.T0 = P.T[0]; B.T1 = P.T[1]; B.eps = P.eps_t;
         B.K = (int)K;
         // chunks of >= 16 samples, about 16384 of them on a long signal (one lane each in the chunk kernels;

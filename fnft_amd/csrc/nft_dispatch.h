@@ -75,6 +75,30 @@ struct KBsPick {
     static constexpr size_t lds_bytes() { return 256 * (sizeof(double) + sizeof(int)); }
     static FA_DEV void body(const Params &p) { body_bs_pick(p); }
 };
+struct KBsPsi {
+    using Params = BsParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_bs_psi(p); }
+};
+struct KInvOp {
+    using Params = InvOpParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 256 * sizeof(double); }
+    static FA_DEV void body(const Params &p) { body_inv_op(p); }
+};
+struct KInvSolitons {
+    using Params = InvDsParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_inv_solitons(p); }
+};
+struct KInvCdt {
+    using Params = InvDsParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_inv_cdt(p); }
+};
 struct KAberthNewton {
     using Params = AberthParams;
     static constexpr int THREADS = 256;

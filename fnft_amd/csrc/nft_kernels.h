@@ -2315,7 +2315,8 @@ FA_DEV void body_resample_combine(const ResampleParams &P)
 struct BsParams {
     const cplx *q;       // D preprocessed samples of one signal
     long long D;
-    int ups;             // 1: BO, 2: CF4_2 (spectral parameter and derivative scaled by 1/2)
+    int ups;             // samples per grid point: 1 BO, 2 CF4_2 and the half-step eigenfunctions of the inverse transform
+    double lscale;       // factor on the spectral parameter (and on a'): 1/2 for CF4_2, 1 otherwise
     double T0, T1, eps;  // eps = (T1 - T0)/(D/ups - 1)
     int K;
     const cplx *lam;     // K eigenvalue candidates
@@ -2325,6 +2326,7 @@ struct BsParams {
     cplx *bnd;           // K*(nchunk+1)*2: phi at the chunk starts, [nchunk] = end of the grid
     cplx *bndp;          // K*(nchunk+1)*2: psi at the same points
     cplx *PHI;           // K*(D/ups+1)*2: phi at every grid point
+    cplx *PSI;           // K*(D/ups+1)*2: psi at every grid point (body_bs_psi only)
     cplx *best;          // K*nchunk*2: {metric, 0}, b of the best point of the chunk
     cplx *a, *aprime, *b;
 };
@@ -2373,7 +2375,7 @@ template <bool BACKWARD> FA_DEV void body_bs_chunk(const BsParams &P)
 {
     const int c = FA_BID * FA_BDIM + FA_TID, e = FA_BID_Y;
     if (c >= P.nchunk) return;
-    const cplx l = P.lam[e] * (P.ups == 2 ? 0.5 : 1.0);
+    const cplx l = P.lam[e] * P.lscale;
     const long long n0 = (long long)c * P.L;
     const long long n1 = (n0 + P.L < P.D) ? n0 + P.L : P.D;
     cplx m00 = cmake(1.0, 0.0), m01 = cmake(0.0, 0.0), m10 = m01, m11 = m00;
@@ -2475,7 +2477,7 @@ template <bool BACKWARD> FA_DEV void body_bs_combine(const BsParams &P)
             bnd[2 * P.nchunk] = p1; bnd[2 * P.nchunk + 1] = p2;
             const cplx av = p1 * ph;
             P.a[e] = av;
-            P.aprime[e] = (d1 * ph + cmake(0.0, tb) * av) * (P.ups == 2 ? 0.5 : 1.0);
+            P.aprime[e] = (d1 * ph + cmake(0.0, tb) * av) * P.lscale;
         } else {
             cplx s1 = zero, s2 = ph;
             for (int g = nl; g-- > 0;) {
@@ -2518,7 +2520,7 @@ FA_DEV void body_bs_phi(const BsParams &P)
 {
     const int c = FA_BID * FA_BDIM + FA_TID, e = FA_BID_Y;
     if (c >= P.nchunk) return;
-    const cplx l = P.lam[e] * (P.ups == 2 ? 0.5 : 1.0);
+    const cplx l = P.lam[e] * P.lscale;
     const long long n0 = (long long)c * P.L;
     const long long n1 = (n0 + P.L < P.D) ? n0 + P.L : P.D;
     const long long Dg = P.D / P.ups;
@@ -2538,6 +2540,32 @@ FA_DEV void body_bs_phi(const BsParams &P)
     }
 }
 
+// psi at every grid point of the chunk, backwards from the chunk's end vector (eigenfunctions of the inverse
+// transform's Darboux step, src/fnft_nsev_inverse.c:963-1004); grid point g precedes sample ups*g
+FA_DEV void body_bs_psi(const BsParams &P)
+{
+    const int c = FA_BID * FA_BDIM + FA_TID, e = FA_BID_Y;
+    if (c >= P.nchunk) return;
+    const cplx l = P.lam[e] * P.lscale;
+    const long long n0 = (long long)c * P.L;
+    const long long n1 = (n0 + P.L < P.D) ? n0 + P.L : P.D;
+    const long long Dg = P.D / P.ups;
+    const cplx *bnd = P.bndp + ((size_t)e * (P.nchunk + 1) + (c + 1)) * 2;
+    cplx s1 = bnd[0], s2 = bnd[1];
+    cplx *PSI = P.PSI + (size_t)e * (Dg + 1) * 2;
+    if (n1 == P.D) { PSI[2 * Dg] = s1; PSI[2 * Dg + 1] = s2; }
+    BsStep U, V;
+    for (long long n = n1; n-- > n0;) {
+        bs_step<false>(P.q[n], l, -P.eps, U, V);
+        const cplx t1 = U.u00 * s1 + U.u01 * s2, t2 = U.u10 * s1 + U.u11 * s2;
+        s1 = t1; s2 = t2;
+        if (n % P.ups == 0) {
+            const long long g = n / P.ups;
+            PSI[2 * g] = s1; PSI[2 * g + 1] = s2;
+        }
+    }
+}
+
 FA_DEV double bs_metric(cplx p1, cplx p2, cplx s1, cplx s2)
 {   // |0.5 log |(phi2/psi2)/(phi1/psi1)||, :644
     const cplx r = c_div(c_div(p2, s2), c_div(p1, s1));
@@ -2550,7 +2578,7 @@ FA_DEV void body_bs_metric(const BsParams &P)
 {
     const int c = FA_BID * FA_BDIM + FA_TID, e = FA_BID_Y;
     if (c >= P.nchunk) return;
-    const cplx l = P.lam[e] * (P.ups == 2 ? 0.5 : 1.0);
+    const cplx l = P.lam[e] * P.lscale;
     const long long n0 = (long long)c * P.L;
     const long long n1 = (n0 + P.L < P.D) ? n0 + P.L : P.D;
     const long long Dg = P.D / P.ups;
@@ -2606,6 +2634,212 @@ FA_DEV void body_bs_pick(const BsParams &P)
         FA_SYNC();
     }
     if (t == 0) P.b[e] = (li[0] != 0x7fffffff) ? bv[2 * li[0] + 1] : cmake(0.0, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fnft_nsev_inverse (src/fnft_nsev_inverse.c): element-wise stages between the DFTs (chirp kernels in DFT mode) of
+// the continuous part, and the Darboux steps of the discrete part.  One kernel, selected by `op`.
+// ---------------------------------------------------------------------------------------------
+enum InvOpCode {
+    INV_PREP = 0,      // :1013-1033 + :251-296  contspec *= Blaschke factors * exp(-i xi pf) (in place) -> FFT order
+    INV_PAD,           // out[i] = i <= i0 ? a[i] : 0
+    INV_SPEC_X,        // fnft__poly_specfact.c:75-108  x = log|P|, 0.5 log(1 + |P|^2), 0.5 log(1 - |P|^2)
+    INV_HILBERT,       // :116-121
+    INV_SPEC_RESP,     // :129-130  exp(x - i y)/M
+    INV_REV_CONJ,      // :135-136  out[i] = conj(a[i0 - i]), i <= i0
+    INV_ITER_FIN,      // :434-438  q / sqrt(1 + kappa |q|^2) / D
+    INV_REVERSE,       // out[i] = a[n-1-i]
+    INV_ITER_PHASE,    // :462-469  phase = arg(a[i]); out[i] = reordered(b)[i] * exp(i phase); block sums of |phase|
+    INV_BTAU,          // :654-657  b = 2 eps contspec / degree1step, end points halved
+    INV_DOUBLE_Q,      // q'[2m] = q[m], q'[2m+1] = q[m+1]: the half steps of compute_eigenfunctions as a signal
+};
+struct InvOpParams {
+    int op;
+    long long n;             // elements
+    const cplx *a, *b;
+    cplx *out, *out2;
+    double s0, s1, s2;       // op-specific scalars
+    long long i0;            // op-specific index
+    int kappa;
+    int K;
+    const cplx *bs;          // K bound states (INV_PREP)
+    int *status;             // bit 3: ill-posed spectral factorization (a warning)
+    double *accum;           // INV_ITER_PHASE: one partial sum per workgroup
+};
+FA_DEV void body_inv_op(const InvOpParams &P)
+{
+    FA_LDS_DECL
+    double *red = (double *)FA_LDS_PTR;
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    const bool act = i < P.n;
+    double mine = 0.0;
+    if (act) {
+        switch (P.op) {
+        case INV_PREP: {
+            const double xi = P.s0 + (double)i * P.s1;
+            cplx c = P.a[i];
+            for (int k = 0; k < P.K; k++) {
+                const cplx bk = P.bs[k];
+                c = c * c_div(cmake(xi - bk.x, -bk.y), cmake(xi - bk.x, bk.y));
+            }
+            double sn, cs;
+            fa_sincos(-xi * P.s2, &sn, &cs);
+            c = c * cmake(cs, sn);
+            P.out[i] = c;
+            const long long h = P.n / 2;
+            P.out2[(i >= h - 1) ? i - (h - 1) : i + (h + 1)] = c;
+        } break;
+        case INV_PAD: P.out[i] = (i <= P.i0) ? P.a[i] : cmake(0.0, 0.0); break;
+        case INV_SPEC_X: {
+            const double tol = 1.4901161193847656e-08;   // sqrt(eps)
+            const double a2 = cnorm2(P.a[i]);
+            cplx x;
+            if (P.kappa == 0) {
+                const double ab = sqrt(a2);
+                if (ab < tol) fa_atomic_or_i32(P.status, 8);
+                x = cmake(log(ab), 0.0);
+            } else if (P.kappa == -1) {
+                x = cmake(0.5 * log(1.0 + a2), 0.0);
+            } else {
+                if (a2 > 1.0 - tol) fa_atomic_or_i32(P.status, 8);
+                const double v = 1.0 - a2;   // 0.5*clog(v): log|v| + i*pi for v < 0
+                x = cmake(0.5 * log(fabs(v)), v < 0.0 ? 0.5 * 3.14159265358979323846 : 0.0);
+            }
+            P.out[i] = x;
+        } break;
+        case INV_HILBERT: {
+            const long long h = P.n / 2;
+            const cplx v = P.a[i];
+            const double m = 1.0 / (double)P.n;
+            cplx r;
+            if (i == 0 || i == h - 1) r = cmake(0.0, 0.0);
+            else if (i < h - 1) r = cmake(v.y * m, -v.x * m);      // * (-i/M)
+            else r = cmake(-v.y * m, v.x * m);                     // * (+i/M)
+            P.out[i] = r;
+        } break;
+        case INV_SPEC_RESP: {
+            const cplx x = P.a[i], y = P.b[i];
+            // exp(x - i*y) / M
+            const double re = x.x + y.y, im = x.y - y.x;
+            double sn, cs;
+            fa_sincos(im, &sn, &cs);
+            const double m = exp(re) / (double)P.n;
+            P.out[i] = cmake(m * cs, m * sn);
+        } break;
+        case INV_REV_CONJ: P.out[i] = cconj(P.a[P.i0 - i]); break;
+        case INV_ITER_FIN: {
+            const cplx q = P.a[i];
+            const double d = 1.0 / (sqrt(1.0 + (double)P.kappa * cnorm2(q)) * (double)P.n);
+            P.out[i] = q * d;
+        } break;
+        case INV_REVERSE: P.out[i] = P.a[P.n - 1 - i]; break;
+        case INV_ITER_PHASE: {
+            const cplx v = P.a[i];
+            const double ph = atan2(v.y, v.x);
+            mine = fabs(ph);
+            const long long h = P.n / 2;
+            const cplx c = P.b[(i <= h) ? i + (h - 1) : i - (h + 1)];
+            double sn, cs;
+            fa_sincos(ph, &sn, &cs);
+            P.out[i] = c * cmake(cs, sn);
+        } break;
+        case INV_BTAU: {
+            const double f = (i == 0 || i == P.n - 1) ? P.s0 : 2.0 * P.s0;
+            P.out[i] = P.a[i] * f;
+        } break;
+        case INV_DOUBLE_Q: P.out[i] = P.a[(i + 1) / 2]; break;
+        default: break;
+        }
+    }
+    if (P.op == INV_ITER_PHASE) {   // deterministic block sums (the host adds them in order)
+        red[FA_TID] = mine;
+        FA_SYNC();
+        for (int h = FA_BDIM / 2; h >= 1; h >>= 1) {
+            if (FA_TID < h) red[FA_TID] += red[FA_TID + h];
+            FA_SYNC();
+        }
+        if (FA_TID == 0) P.accum[FA_BID] = red[0];
+    }
+}
+
+// Discrete part, src/fnft_nsev_inverse.c:680-903.  One lane per sample n.
+struct InvDsParams {
+    long long D;
+    int K;
+    const cplx *bs;          // K bound states, sorted by descending imaginary part
+    const cplx *nc;          // K norming constants
+    double T0, eps_t;
+    long long zc;            // first sample with t >= 0
+    cplx *q;                 // D samples: seed in (CDT), result out
+    cplx *work;              // K*D (pure solitons: rho_k) or 2*K*D (CDT: S1, S2)
+    const cplx *PHI, *PSI;   // K*D*2 each (CDT)
+};
+// pure multi-soliton, :797-842: q(t) by the recursive Darboux formula in rho_k = b_k exp(2 i lam_k t); samples
+// before the zero crossing use the mirrored recursion (1/b_k, -t) and the conjugate
+FA_DEV void body_inv_solitons(const InvDsParams &P)
+{
+    const long long n = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (n >= P.D) return;
+    const double t = P.T0 + P.eps_t * (double)n;
+    const bool right = n >= P.zc;
+    const double sg = right ? 1.0 : -1.0;
+    cplx *rho = P.work + n;   // rho_k at work[k*D + n]
+    for (int k = 0; k < P.K; k++) {
+        const cplx l = P.bs[k];
+        const cplx b = right ? P.nc[k] : c_div(cmake(1.0, 0.0), P.nc[k]);
+        // exp(sg * 2 i l t)
+        double sn, cs;
+        fa_sincos(sg * 2.0 * l.x * t, &sn, &cs);
+        const double m = exp(-sg * 2.0 * l.y * t);
+        rho[(size_t)k * P.D] = b * cmake(m * cs, m * sn);
+    }
+    cplx qt = cmake(0.0, 0.0);
+    for (int i = 0; i < P.K; i++) {
+        const cplx li = P.bs[i];
+        const cplx r = rho[(size_t)i * P.D], rc = cconj(r);
+        const cplx f = cmake(0.0, 2.0 * li.y) * (1.0 / (1.0 + cnorm2(r)));
+        qt = qt + (rc * f) * cmake(0.0, 2.0);
+        for (int j = i + 1; j < P.K; j++) {
+            const cplx lj = P.bs[j];
+            const cplx rj = rho[(size_t)j * P.D];
+            const cplx num = (lj - li) * rj + (rj - r) * f;
+            const cplx den = lj - cconj(li) - (cmake(1.0, 0.0) + rc * rj) * f;
+            rho[(size_t)j * P.D] = c_div(num, den);
+        }
+    }
+    P.q[n] = right ? qt : cconj(qt);
+}
+// Darboux steps on top of a seed potential, :864-889, from the eigenfunctions phi, psi of the seed at every sample
+FA_DEV void body_inv_cdt(const InvDsParams &P)
+{
+    const long long n = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (n >= P.D) return;
+    cplx *S1 = P.work + n, *S2 = P.work + (size_t)P.K * P.D + n;
+    cplx qn = P.q[n];
+    for (int i = 0; i < P.K; i++) {
+        const cplx li = P.bs[i];
+        const cplx *ph = P.PHI + ((size_t)i * P.D + n) * 2, *ps = P.PSI + ((size_t)i * P.D + n) * 2;
+        cplx p1 = ph[0], p2 = ph[1], s1 = ps[0], s2 = ps[1];
+        for (int j = 0; j < i; j++) {
+            const cplx a = li - S1[(size_t)j * P.D], b = S2[(size_t)j * P.D], ac = li - cconj(S1[(size_t)j * P.D]);
+            const cplx t1 = a * p1 - b * p2;
+            p2 = cconj(b) * p1 + ac * p2;
+            p1 = t1;
+            const cplx t2 = a * s1 - b * s2;
+            s2 = cconj(b) * s1 + ac * s2;
+            s1 = t2;
+        }
+        const cplx nci = P.nc[i];
+        const cplx beta = c_div(p1 - nci * s1, p2 - nci * s2);
+        const double ab = cnorm2(beta);
+        const double inv = 1.0 / (1.0 + ab);
+        const cplx s1v = (li * ab + cconj(li)) * inv;
+        const cplx s2v = (cmake(0.0, 2.0 * li.y) * beta) * inv;
+        S1[(size_t)i * P.D] = s1v;
+        S2[(size_t)i * P.D] = s2v;
+        qn = qn - cmake(0.0, 2.0) * s2v;
+    }
+    P.q[n] = qn;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -174,6 +174,56 @@ FNFT_INT fnft_nsev(const FNFT_UINT D, FNFT_COMPLEX *const q, FNFT_REAL const *co
                    FNFT_COMPLEX *const normconsts_or_residues, const FNFT_INT kappa,
                    fnft_nsev_opts_t *opts);
 
+/* ---------------------------------------------------------------------------------------- */
+/* 1b. fnft_nsev_inverse (round 2; SURVEY 8f rank 4: the caller below the forward path)      */
+/* ---------------------------------------------------------------------------------------- */
+
+/* include/fnft_nsev_inverse.h:58-62 */
+typedef enum {
+    fnft_nsev_inverse_cstype_REFLECTION_COEFFICIENT,
+    fnft_nsev_inverse_cstype_B_OF_XI,
+    fnft_nsev_inverse_cstype_B_OF_TAU
+} fnft_nsev_inverse_cstype_t;
+/* include/fnft_nsev_inverse.h:76-79 */
+typedef enum {
+    fnft_nsev_inverse_dstype_NORMING_CONSTANTS,
+    fnft_nsev_inverse_dstype_RESIDUES
+} fnft_nsev_inverse_dstype_t;
+/* include/fnft_nsev_inverse.h:110-115 */
+typedef enum {
+    fnft_nsev_inverse_csmethod_DEFAULT,
+    fnft_nsev_inverse_csmethod_TFMATRIX_CONTAINS_REFL_COEFF,
+    fnft_nsev_inverse_csmethod_TFMATRIX_CONTAINS_AB_FROM_ITER,
+    fnft_nsev_inverse_csmethod_USE_SEED_POTENTIAL_INSTEAD
+} fnft_nsev_inverse_csmethod_t;
+/* include/fnft_nsev_inverse.h:155-162 (same fields, same order) */
+typedef struct {
+    fnft_nse_discretization_t discretization;
+    fnft_nsev_inverse_cstype_t contspec_type;
+    fnft_nsev_inverse_csmethod_t contspec_inversion_method;
+    fnft_nsev_inverse_dstype_t discspec_type;
+    FNFT_UINT max_iter;
+    FNFT_UINT oversampling_factor;
+} fnft_nsev_inverse_opts_t;
+
+/* include/fnft_nsev_inverse.h:176 (src/fnft_nsev_inverse.c:26-38): 2SPLIT2A, reflection coefficient, DEFAULT method,
+ * norming constants, max_iter 100, oversampling_factor 8 */
+fnft_nsev_inverse_opts_t fnft_nsev_inverse_default_opts(void);
+/* include/fnft_nsev_inverse.h:199-204 (src/fnft_nsev_inverse.c:40-65): the xi-grid XI[0..1] that makes the M samples
+ * of the continuous spectrum an M-point FFT grid for D samples on T */
+FNFT_INT fnft_nsev_inverse_XI(const FNFT_UINT D, FNFT_REAL const *const T, const FNFT_UINT M, FNFT_REAL *const XI,
+                              const fnft_nse_discretization_t discretization);
+/* include/fnft_nsev_inverse.h:275-286 (src/fnft_nsev_inverse.c:121-248).  HOST buffers owned by the caller; like the
+ * reference, contspec[M] is modified (boundary phase factors removed, Blaschke factors applied).  D a power of two,
+ * M even and >= D, discretization 2SPLIT2A or 2SPLIT2_MODAL.  Argument checks in the reference's order with its return
+ * codes.  On the GPU: the M-point and spectral-factorization DFTs (any length), the element-wise stages, the layer
+ * peeling's products (fnft__nse_finvscatter), the multi-soliton recursion, the seed's eigenfunctions and the Darboux
+ * steps.  Limit: DFT lengths up to 2^23 (spectral factorization at oversampling 8: D <= 2^19). */
+FNFT_INT fnft_nsev_inverse(const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI,
+                           FNFT_UINT const K, FNFT_COMPLEX const *const bound_states,
+                           FNFT_COMPLEX const *const normconsts_or_residues, const FNFT_UINT D, FNFT_COMPLEX *const q,
+                           FNFT_REAL const *const T, const FNFT_INT kappa, fnft_nsev_inverse_opts_t *opts_ptr);
+
 /* ======================================================================================== */
 /* 2. Private-layer seam (symbols the reference's libfnft.so also exports)                  */
 /* ======================================================================================== */
@@ -218,6 +268,14 @@ FNFT_INT fnft__poly_fmult_two_polys2x2(const FNFT_UINT deg, FNFT_COMPLEX const *
  * (defocusing) or D is not a power of two. */
 FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer_matrix, FNFT_COMPLEX *const q,
                                const FNFT_REAL eps_t, const FNFT_INT kappa, const fnft_nse_discretization_t discretization);
+
+/* include/private/fnft__poly_specfact.h (src/private/fnft__poly_specfact.c:25-140): spectral factor of
+ * |P|^2 (kappa = 0), 1 + |P|^2 (kappa = -1) or 1 - |P|^2 (kappa = +1) on the unit circle by the cepstral method on a
+ * grid of next_fast_size((deg+1)*oversampling_factor) points (the reference's 2-3-5-smooth FFT length, as a DFT of
+ * that length on the GPU).  poly, result: deg+1 coefficients, host.  Prints the reference's "Ill-posed spectral
+ * factorization problem." warning through the printf hook. */
+FNFT_INT fnft__poly_specfact(const FNFT_UINT deg, FNFT_COMPLEX const *const poly, FNFT_COMPLEX *const result,
+                             const FNFT_UINT oversampling_factor, const FNFT_INT kappa);
 
 /* include/private/fnft__poly_chirpz.h:61 (src/private/fnft__poly_chirpz.c:33-105).
  * A and W are passed as pointers to {re, im} here (complex-by-value does not cross every FFI);

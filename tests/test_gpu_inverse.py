@@ -1,0 +1,181 @@
+"""fnft_nsev_inverse through the C ABI on the GPU: the reference's own tests of test/fnft_nsev_inverse (same cases,
+same error bounds as tests/test_inverse_oracle.py runs against the oracle), agreement with the oracle on the same
+inputs, and the fnft__poly_specfact seam."""
+import numpy as np
+import pytest
+
+import inverse_cases as IC
+import signals as S
+
+pytestmark = pytest.mark.gpu
+TAGS = ("2split2A", "2split2_modal")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from fnft_amd import capi as c
+    c.load()
+    c.silence_errors()
+    return c
+
+
+@pytest.fixture(scope="module")
+def INV():
+    from oracle import inverse
+    return inverse
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import load_oracle
+    return load_oracle()
+
+
+def xi_of(capi):
+    def f(D, T, M):
+        rc, XI = capi.nsev_inverse_XI(D, T, M)
+        assert rc == 0
+        return XI
+    return f
+
+
+def run(capi, case, INV=None, tol_vs_oracle=None, orc=None):
+    cs = None if case.get("contspec") is None else np.array(case["contspec"], np.complex128)
+    rc, q = capi.fnft_nsev_inverse(case["M"], cs, case.get("XI"), case.get("bound_states"), case.get("normconsts"),
+                                   case["D"], case["T"], case["kappa"], case["opts"], q_seed=case.get("q_seed"))
+    assert rc == 0, capi.last_error()
+    err = S.rel_err(q, case["q_exact"])
+    assert err < case["bound"], (err, case["bound"])
+    if INV is not None:
+        scatter_a = None
+        if orc is not None:
+            def scatter_a(qq, T, lam):
+                rc2, a, _ap, _b = orc.scatter_bound_states(qq, T, lam, 1, skip_b=True)
+                assert rc2 == 0
+                return a
+        cs2 = None if case.get("contspec") is None else np.array(case["contspec"], np.complex128)
+        rc, qo = INV.fnft_nsev_inverse(case["M"], cs2, case.get("XI"), case.get("bound_states"), case.get("normconsts"),
+                                       case["D"], case["T"], case["kappa"], case["opts"], q_seed=case.get("q_seed"),
+                                       scatter_a=scatter_a)
+        assert rc == 0
+        d = S.rel_err(q, qo)
+        assert d < tol_vs_oracle, d
+        if cs is not None:   # the reference modifies the caller's contspec; so do the oracle and the library
+            assert S.rel_err(cs, cs2) < 1e-12
+    return err
+
+
+def test_XI(capi, INV):
+    for D, T, M in ((8, [0.0, 7.0], 10), (512, [-2.0, 2.0], 2048), (4096, [-25.0, 25.0], 4096)):
+        rc, XI = capi.nsev_inverse_XI(D, T, M)
+        assert rc == 0
+        assert np.allclose(XI, INV.nsev_inverse_XI(D, T, M), rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("n", (2048, 4096))
+@pytest.mark.parametrize("tag", TAGS)
+def test_sech_defocusing_data(capi, INV, tag, n):
+    run(capi, IC.sech_defocusing(tag, n), INV, 1e-9)
+
+
+@pytest.mark.parametrize("D", (512, 1024))
+@pytest.mark.parametrize("tag", TAGS)
+def test_truncated_soliton(capi, INV, tag, D):
+    run(capi, IC.truncated_soliton(tag, D, xi_of(capi)), INV, 1e-9)
+
+
+@pytest.mark.parametrize("step", range(4))
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("kind", ("B_of_tau", "b_of_xi"))
+def test_B_of_tau_or_b_of_xi(capi, INV, kind, tag, step):
+    run(capi, IC.b_cases(kind, False, tag, step, xi_of(capi)), INV, 1e-9)
+
+
+@pytest.mark.parametrize("step", range(4))
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("kind", ("B_of_tau", "b_of_xi"))
+def test_B_of_tau_or_b_of_xi_with_discrete_spectrum(capi, INV, kind, tag, step):
+    run(capi, IC.b_cases(kind, True, tag, step, xi_of(capi)), INV, 1e-8)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("sign", ("focusing", "defocusing"))
+def test_against_forward(capi, INV, sign, tag):
+    for idx in range(IC.n_against_forward(sign, tag)):
+        case = IC.against_forward(sign, tag, idx)
+        XI = xi_of(capi)(case["D"], case["T"], case["M"])
+        rc, cs = capi.fnft_nsev(case["q_exact"], case["T"], case["M"], XI, kappa=case["kappa"],
+                                discretization=case["forward"], contspec_type="REFLECTION_COEFFICIENT")
+        assert rc == 0
+        case.update(contspec=cs[:case["M"]], XI=XI)
+        run(capi, case, INV, 1e-11)
+
+
+@pytest.mark.parametrize("D", (512, 1024))
+@pytest.mark.parametrize("dstype", ("NORMING_CONSTANTS", "RESIDUES"))
+@pytest.mark.parametrize("tag", TAGS)
+def test_against_forward_with_discrete_spectrum(capi, INV, orc, tag, dstype, D):
+    case = IC.against_forward_w_discrete(tag, dstype, D)
+    XI = xi_of(capi)(D, case["T"], case["M"])
+    out = capi.fnft_nsev_ds(case["q_exact"], case["T"], discretization="2SPLIT4B", M=case["M"], XI=XI, K=10)
+    rc, bs, nc, res, cs = out
+    assert rc == 0 and bs.size == 3
+    case.update(contspec=cs[:case["M"]], XI=XI, bound_states=bs, normconsts=nc if dstype == "NORMING_CONSTANTS" else res)
+    run(capi, case, INV, 1e-7, orc)
+
+
+@pytest.mark.parametrize("D", (512, 1024))
+@pytest.mark.parametrize("dstype", ("NORMING_CONSTANTS", "RESIDUES"))
+def test_addsoliton_cdt(capi, INV, D, dstype):
+    run(capi, IC.addsoliton_cdt(D, dstype), INV, 1e-9)
+
+
+@pytest.mark.parametrize("dstype", ("NORMING_CONSTANTS", "RESIDUES"))
+def test_multisoliton_cdt(capi, INV, dstype):
+    run(capi, IC.multisoliton_cdt(dstype), INV, 1e-12)
+
+
+def test_full_size_round_trip(capi):
+    """D = 2^18: contspec of a sech pulse by the forward transform, back by the inverse (REFL_COEFF method, M = 2D)."""
+    D = 1 << 18
+    T = [-32.0, 32.0]
+    t = S.tgrid(T, D)
+    q0 = 0.4 / np.cosh(t) * np.exp(-1j * t)
+    rc, XI = capi.nsev_inverse_XI(D, T, 2 * D, "2SPLIT2_MODAL")
+    assert rc == 0
+    rc, cs = capi.fnft_nsev(q0, T, 2 * D, XI, kappa=1, discretization="2SPLIT2_MODAL",
+                            contspec_type="REFLECTION_COEFFICIENT")
+    assert rc == 0
+    rc, q = capi.fnft_nsev_inverse(2 * D, cs[:2 * D].copy(), XI, None, None, D, T, 1,
+                                   {"discretization": "2SPLIT2_MODAL"})
+    assert rc == 0, capi.last_error()
+    assert S.rel_err(q, q0) < 1e-5   # the A(z) = 1 construction is approximate: not a round-off bound
+
+
+@pytest.mark.parametrize("kappa", (-1, 0, 1))
+@pytest.mark.parametrize("deg", (7, 255, 1000))
+def test_poly_specfact_vs_oracle(capi, INV, kappa, deg):
+    rng = np.random.default_rng(deg + kappa)
+    p = (rng.standard_normal(deg + 1) + 1j * rng.standard_normal(deg + 1)) * (0.3 / np.sqrt(deg + 1))
+    if kappa == 0:
+        p[0] += 2.0
+    rc, r = capi.poly_specfact(p, 8, kappa)
+    assert rc == 0, capi.last_error()
+    ro, _w = INV.poly_specfact(p, 8, kappa)
+    assert S.rel_err(r, ro) < 1e-11
+
+
+def test_argument_checks_follow_the_reference(capi):
+    q8 = np.zeros(8, np.complex128)
+    f = capi.fnft_nsev_inverse
+    assert f(8, None, [0, 1], None, None, 8, [0, 1], 1)[0] == 2
+    assert f(9, np.zeros(9, complex), [0, 1], None, None, 8, [0, 1], 1)[0] == 2
+    assert f(4, np.zeros(4, complex), [0, 1], None, None, 8, [0, 1], 1)[0] == 2
+    assert f(12, np.zeros(12, complex), [0, 1], None, None, 12, [0, 1], 1)[0] == 2
+    assert f(8, q8.copy(), [0, 1], None, None, 8, [1, 0], 1)[0] == 2
+    assert f(8, q8.copy(), [0, 1], None, None, 8, [0, 1], 0)[0] == 2
+    assert f(8, q8.copy(), [0, 1], [1j], [1.0], 8, [0, 1], -1)[0] == 7
+    assert f(8, q8.copy(), [0, 1], [-1j], [1.0], 8, [0, 1], 1)[0] == 7
+    assert f(0, None, None, None, None, 8, [0, 1], 1)[0] == 7
+    assert f(8, q8.copy(), [0, 1], None, None, 8, [0, 1], 1, {"discretization": "2SPLIT4B"})[0] == 2
+    assert f(8, q8.copy(), [0, 1], [1j, 1j], [1.0, 1.0], 8, [0, 1], 1)[0] == -7     # multiplicity, :756-761
