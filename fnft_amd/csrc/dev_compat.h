@@ -69,6 +69,10 @@ FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
     return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
+// wave shuffles of doubles (body_peel_leaf: one wave per workgroup)
+FA_DEV double fa_shfl(double v, int src) { return __shfl(v, src, 64); }
+FA_DEV double fa_shfl_up1(double v) { return __shfl_up(v, 1, 64); }
+FA_DEV double fa_shfl_down1(double v) { return __shfl_down(v, 1, 64); }
 // hardware reciprocals (v_rcp_f64 / v_rcp_f32): starting values, refine where accuracy matters
 FA_DEV double fa_rcp_approx(double x) { return __builtin_amdgcn_rcp(x); }
 FA_DEV float fa_rcp_approx_f32(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -138,6 +142,10 @@ FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 FA_DEV double fa_rcp_approx(double x) { return 1.0 / x; }
+// the lane emulator runs no kernel that shuffles (body_peel_leaf is GPU-only): placeholders for the parser
+FA_DEV double fa_shfl(double v, int) { return v; }
+FA_DEV double fa_shfl_up1(double v) { return v; }
+FA_DEV double fa_shfl_down1(double v) { return v; }
 FA_DEV float fa_rcp_approx_f32(float x) { return 1.0f / x; }
 FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
 FA_DEV double fa_uniform(double x) { return x; }

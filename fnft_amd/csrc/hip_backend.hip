@@ -6,7 +6,6 @@
 #include <tuple>
 
 #include "hip_be.h"
-#include "nft_inverse.h"
 #include "nft_nsev_inverse.h"
 #include "../../include/fnft_amd.h"
 
@@ -536,17 +535,7 @@ FNFT_INT fnft__poly_fmult_two_polys2x2(const FNFT_UINT deg, FNFT_COMPLEX const *
 }
 
 // include/private/fnft__nse_finvscatter.h (src/private/fnft__nse_finvscatter.c:234-366): samples from a transfer
-// matrix by layer peeling; products of degree >= kInvGpuDeg on the GPU, smaller ones on the host
-struct InvProduct {
-    static constexpr size_t kInvGpuDeg = 512;
-    int operator()(size_t deg, const std::complex<double> *A, size_t As, const std::complex<double> *B, size_t Bs,
-                   std::complex<double> *C, size_t Cs)
-    {
-        if (deg < kInvGpuDeg) { nft_host_product2x2(deg, A, As, B, Bs, C, Cs); return 0; }
-        return fnft__poly_fmult_two_polys2x2(deg, A, As, B, Bs, C, Cs, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
-    }
-};
-
+// matrix by layer peeling, every array on the device (NftLayerPeelingDev, nft_nsev_inverse.h)
 FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer_matrix, FNFT_COMPLEX *const q,
                                const FNFT_REAL eps_t, const FNFT_INT kappa, const fnft_nse_discretization_t discretization)
 {
@@ -561,10 +550,12 @@ FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer
     const bool modal = discretization == fnft_nse_discretization_2SPLIT2_MODAL;
     if (!modal && discretization != fnft_nse_discretization_2SPLIT2A) return FNFT_EC_INVALID_ARGUMENT;
     if (current_device() < 0) return FNFT_EC_OTHER;
-    InvProduct prod;
-    NftLayerPeeling<InvProduct> lp(prod, eps_t, (int)kappa, modal ? 1 : 0);
-    lp.peel(deg, transfer_matrix, deg + 1, nullptr, 0, q);
-    return lp.rc;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    NftLayerPeelingDev<HipBackend> lp(be, eps_t, (int)kappa, modal ? 1 : 0);
+    const int rc = lp.run_host(deg, transfer_matrix, q);
+    if (be.failed) return FNFT_EC_OTHER;
+    return rc;
 }
 
 // ---- fnft_nsev_inverse (driver: fnft_nsev_inverse_host.c) ---------------------------------------------------------

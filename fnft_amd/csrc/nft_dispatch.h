@@ -87,6 +87,24 @@ struct KInvOp {
     static constexpr size_t lds_bytes() { return 256 * sizeof(double); }
     static FA_DEV void body(const Params &p) { body_inv_op(p); }
 };
+struct KPeelImport {
+    using Params = PeelIoParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_peel_import(p); }
+};
+struct KPeelExport {
+    using Params = PeelIoParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_peel_export(p); }
+};
+struct KPeelLeaf {
+    using Params = PeelLeafParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_peel_leaf(p); }
+};
 struct KInvSolitons {
     using Params = InvDsParams;
     static constexpr int THREADS = 256;

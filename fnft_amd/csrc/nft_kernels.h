@@ -2762,6 +2762,157 @@ FA_DEV void body_inv_op(const InvOpParams &P)
     }
 }
 
+// ---- layer peeling on the device (src/private/fnft__nse_finvscatter.c:66-232) ------------------------------------
+// Two factors of a 2x2 polynomial product from arbitrary strided device arrays into level 0 of a plan with n = 2
+// matrices of degree d (body/tail layout), and the product back out, multiplied by 2^W (un-normalised).
+struct PeelIoParams {
+    const cplx *A, *B;        // four entries of d+1 coefficients each, highest power first
+    long long As, Bs;         // entry strides
+    long long d;
+    cplx *body, *tail;        // import: level 0 of the plan (plane = 2*d)
+    double *scale;
+    int *wexp;
+    const cplx *src;          // export: the plan's result layout, four entries of dout+1 = 2d+1
+    const int *W;             // export: exponent taken out by the plan
+    cplx *C;                  // export: four entries at stride Cs
+    long long Cs;
+};
+FA_DEV void body_peel_import(const PeelIoParams &P)
+{
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long w = P.d + 1;
+    if (i >= 8 * w) return;
+    const int e = (int)(i / (2 * w));
+    const long long r = i % (2 * w);
+    const int m = (int)(r / w);
+    const long long k = r % w;
+    const cplx v = m == 0 ? P.A[(long long)e * P.As + k] : P.B[(long long)e * P.Bs + k];
+    if (k < P.d) P.body[(long long)e * 2 * P.d + (long long)m * P.d + k] = v;
+    else P.tail[e * 2 + m] = v;
+    if (i < 2) { P.scale[i] = 1.0; P.wexp[i] = 0; }
+}
+FA_DEV void body_peel_export(const PeelIoParams &P)
+{
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long w = 2 * P.d + 1;
+    if (i >= 4 * w) return;
+    const int e = (int)(i / w);
+    const long long k = i % w;
+    P.C[(long long)e * P.Cs + k] = P.src[i] * pow2i(P.W[0]);
+}
+
+// One block of d <= 256 samples peeled off by ONE wave, coefficient arrays in registers (4 consecutive indices per
+// lane), one sample per step: with Q = -kappa conj(T21(0)/T11(0)) (:158-176) the last step matrix is divided out,
+//   T1j <- scl (T1j - Q T2j),   T2j <- scl (kappa Q* T1j + T2j) / z,          scl = 1/sqrt(1 + kappa |Q|^2),
+// and the same matrix is multiplied onto the block's inverse (up to a power of z), which the caller one level up
+// needs (:144-156).  In exact arithmetic this is what the reference's recursion computes for the block.
+struct PeelLeafParams {
+    const cplx *T;            // four entries of d+1 coefficients at stride Ts (highest power first)
+    long long Ts;
+    int d;
+    cplx *Ti;                 // NULL or four entries of d+1 coefficients at stride Tis
+    long long Tis;
+    cplx *q;                  // d samples
+    double eps_t;
+    int kappa, modal;
+    int *status;              // bit 4: a reconstructed sample violates 1 + kappa |eps q|^2 > 0 (:173-176)
+};
+FA_DEV cplx fa_shfl_c(cplx v, int src) { return cmake(fa_shfl(v.x, src), fa_shfl(v.y, src)); }
+FA_DEV cplx fa_shfl_up_c(cplx v) { return cmake(fa_shfl_up1(v.x), fa_shfl_up1(v.y)); }
+FA_DEV cplx fa_shfl_down_c(cplx v) { return cmake(fa_shfl_down1(v.x), fa_shfl_down1(v.y)); }
+FA_DEV void body_peel_leaf(const PeelLeafParams &P)
+{
+    constexpr int R = 4;
+    const int lane = FA_TID;            // 64 lanes
+    const int d = P.d;
+    // element K (1 <= K <= d) of every array lives in lane (K-1)/R, slot (K-1)%R; element 0 in `t0` of every lane
+    cplx t[4][R], a[4][R], t0[4];
+    const cplx zero = cmake(0.0, 0.0);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        t0[e] = P.T[(long long)e * P.Ts];
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            const int K = lane * R + s + 1;
+            t[e][s] = (K <= d) ? P.T[(long long)e * P.Ts + K] : zero;
+            a[e][s] = (K == d && (e == 0 || e == 3)) ? cmake(1.0, 0.0) : zero;   // identity: constant terms
+        }
+    }
+    cplx a0[4] = {zero, zero, zero, zero};   // element 0 of the inverse
+    const int lastLane = (d - 1) / R, lastSlot = (d - 1) % R;
+    bool bad = false;
+    for (int step = 0; step < d; step++) {
+        // constant terms T11[d], T21[d]
+        cplx c11 = zero, c21 = zero;
+#pragma unroll
+        for (int s = 0; s < R; s++)
+            if (s == lastSlot) { c11 = t[0][s]; c21 = t[2][s]; }
+        c11 = fa_shfl_c(c11, lastLane);
+        c21 = fa_shfl_c(c21, lastLane);
+        const cplx Q = cconj(c_div(c21, c11)) * (double)(-P.kappa);
+        const double aQ2 = cnorm2(Q);
+        const double den = 1.0 + (double)P.kappa * aQ2;
+        if (!(den > 0.0)) bad = true;
+        const double scl = 1.0 / sqrt(den);
+        if (lane == 0) {
+            cplx qv;
+            if (P.modal) qv = Q * (1.0 / P.eps_t);
+            else {
+                const double aQ = sqrt(aQ2);
+                const double f = (aQ > 0.0) ? atan(aQ) / (aQ * P.eps_t) : 1.0 / P.eps_t;   // atan|Q| e^{i arg Q} / eps
+                qv = Q * f;
+            }
+            P.q[d - 1 - step] = qv;
+        }
+        const cplx kQc = cconj(Q) * (double)P.kappa;
+        // T: row 1 element-wise, row 2 takes the left neighbour (division by z)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {            // columns: entries (0, 2) and (1, 3)
+            const int e1 = j, e2 = 2 + j;
+            cplx n1[R], n2[R];
+            // left neighbours of the lane's first slot
+            cplx l1 = fa_shfl_up_c(t[e1][R - 1]), l2 = fa_shfl_up_c(t[e2][R - 1]);
+            if (lane == 0) { l1 = t0[e1]; l2 = t0[e2]; }
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                n1[s] = (t[e1][s] - Q * t[e2][s]) * scl;
+                const cplx p1 = (s == 0) ? l1 : t[e1][s - 1], p2 = (s == 0) ? l2 : t[e2][s - 1];
+                n2[s] = (kQc * p1 + p2) * scl;
+            }
+#pragma unroll
+            for (int s = 0; s < R; s++) { t[e1][s] = n1[s]; t[e2][s] = n2[s]; }
+            // inverse: row 1 takes the right neighbour (multiplication by z), row 2 element-wise
+            cplx r1 = fa_shfl_down_c(a[e1][0]), r2 = fa_shfl_down_c(a[e2][0]);
+            if (lane == 63) { r1 = zero; r2 = zero; }
+            cplx m1[R], m2[R];
+            const cplx na0_1 = (a[e1][0] - Q * a[e2][0]) * scl;   // new element 0 from element 1 (lane 0, slot 0)
+            const cplx na0_2 = (kQc * a0[e1] + a0[e2]) * scl;
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const cplx x1 = (s == R - 1) ? r1 : a[e1][s + 1], x2 = (s == R - 1) ? r2 : a[e2][s + 1];
+                m1[s] = (x1 - Q * x2) * scl;
+                m2[s] = (kQc * a[e1][s] + a[e2][s]) * scl;
+            }
+#pragma unroll
+            for (int s = 0; s < R; s++) { a[e1][s] = m1[s]; a[e2][s] = m2[s]; }
+            a0[e1] = fa_shfl_c(na0_1, 0);
+            a0[e2] = fa_shfl_c(na0_2, 0);
+        }
+    }
+    if (bad && lane == 0) fa_atomic_or_i32(P.status, 16);
+    if (P.Ti) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (lane == 0) P.Ti[(long long)e * P.Tis] = a0[e];
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int K = lane * R + s + 1;
+                if (K <= d) P.Ti[(long long)e * P.Tis + K] = a[e][s];
+            }
+        }
+    }
+}
+
 // Discrete part, src/fnft_nsev_inverse.c:680-903.  One lane per sample n.
 struct InvDsParams {
     long long D;

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <complex>
 #include <cstring>
+#include <map>
+#include <new>
 #include <vector>
 
 #include "nft_plan.h"
@@ -24,6 +26,127 @@ inline size_t nft_next_fast_size(size_t n)
         if (m <= 1) return n;
     }
 }
+
+// Layer peeling with every array on the device (src/private/fnft__nse_finvscatter.c:66-232): the recursion of
+// (steps 1-4 below) issued from the host without a single synchronisation -- blocks of up to kLeaf samples by the
+// one-wave leaf kernel (body_peel_leaf), the 2x2 polynomial products above that by resident plans (one per degree,
+// n = 2 matrices: the tree's general pair kernels), factors and results moved between the caller's strided arrays
+// and the plans' layout by two small kernels.  Work arrays: one set per recursion depth (depth-first order on one
+// stream, so siblings reuse them).
+template <class BE> class NftLayerPeelingDev {
+public:
+    static constexpr size_t kLeaf = 256;
+    BE &be;
+    double eps_t;
+    int kappa, modal;
+    int rc = NFT_SUCCESS;
+    int *d_status = nullptr;
+    std::map<size_t, NftPlan<BE> *> plans;
+    struct Work { cplx *T2i = nullptr, *T1 = nullptr, *T1i = nullptr; };
+    std::vector<Work> work;
+
+    NftLayerPeelingDev(BE &b, double eps, int kap, int is_modal) : be(b), eps_t(eps), kappa(kap), modal(is_modal) {}
+    ~NftLayerPeelingDev() { destroy(); }
+    void destroy()
+    {
+        for (auto &kv : plans) { kv.second->destroy(); delete kv.second; }
+        plans.clear();
+        for (auto &w : work) { be.free(w.T2i); be.free(w.T1); be.free(w.T1i); }
+        work.clear();
+        be.free(d_status);
+        d_status = nullptr;
+    }
+    int init(size_t deg)
+    {
+        d_status = (int *)be.alloc(4 * sizeof(int));
+        if (!d_status) return NFT_EC_NOMEM;
+        be.memset0(d_status, 4 * sizeof(int));
+        for (size_t d = deg; d > kLeaf; d /= 2) {
+            Work w;
+            w.T2i = (cplx *)be.alloc(4 * (d + 1) * sizeof(cplx));
+            w.T1 = (cplx *)be.alloc(4 * (2 * d + 1) * sizeof(cplx));
+            w.T1i = (cplx *)be.alloc(4 * (d / 2 + 1) * sizeof(cplx));
+            work.push_back(w);
+            if (!w.T2i || !w.T1 || !w.T1i) return NFT_EC_NOMEM;
+        }
+        return NFT_SUCCESS;
+    }
+    NftPlan<BE> *plan_for(size_t deg)
+    {
+        auto it = plans.find(deg);
+        if (it != plans.end()) return it->second;
+        NftPlan<BE> *pl = new (std::nothrow) NftPlan<BE>(be, 2, 0, 1, -1, (int)deg);
+        if (!pl) { rc = NFT_EC_NOMEM; return nullptr; }
+        const int r = pl->init();
+        if (r != NFT_SUCCESS) { rc = r; pl->destroy(); delete pl; return nullptr; }
+        plans[deg] = pl;
+        return pl;
+    }
+    // C (four entries of 2 deg + 1 coefficients at stride Cs) = A * B (four entries of deg + 1 at strides As, Bs)
+    void prod(size_t deg, const cplx *A, size_t As, const cplx *B, size_t Bs, cplx *C, size_t Cs)
+    {
+        if (rc != NFT_SUCCESS) return;
+        NftPlan<BE> *pl = plan_for(deg);
+        if (!pl) return;
+        PeelIoParams P;
+        std::memset(&P, 0, sizeof(P));
+        P.A = A; P.B = B; P.As = (long long)As; P.Bs = (long long)Bs; P.d = (long long)deg;
+        P.body = pl->body[0]; P.tail = pl->tail[0]; P.scale = pl->scale[0]; P.wexp = pl->wexp[0];
+        be.template run<KPeelImport>((int)((8 * (deg + 1) + 255) / 256), 1, P);
+        pl->cur = 0;
+        pl->ne = 4;
+        pl->start_n = pl->n0;
+        pl->start_d = deg;
+        const int r = pl->run_tree();
+        if (r != NFT_SUCCESS) { rc = r; return; }
+        pl->export_tm();
+        P.src = pl->tm_out; P.W = pl->wexp[pl->cur]; P.C = C; P.Cs = (long long)Cs;
+        be.template run<KPeelExport>((int)((4 * (2 * deg + 1) + 255) / 256), 1, P);
+    }
+    // T: four entries of deg+1 coefficients at stride Ts; Ti (may be NULL): the inverse up to a power of z, four
+    // entries of deg+1 at stride Tis; q: deg samples.  All device pointers.
+    void peel(size_t deg, const cplx *T, size_t Ts, cplx *Ti, size_t Tis, cplx *q, size_t depth = 0)
+    {
+        if (rc != NFT_SUCCESS) return;
+        if (deg <= kLeaf) {
+            PeelLeafParams L;
+            std::memset(&L, 0, sizeof(L));
+            L.T = T; L.Ts = (long long)Ts; L.d = (int)deg; L.Ti = Ti; L.Tis = (long long)Tis; L.q = q;
+            L.eps_t = eps_t; L.kappa = kappa; L.modal = modal; L.status = d_status;
+            be.template run<KPeelLeaf>(1, 1, L);
+            return;
+        }
+        const size_t h = deg / 2;
+        Work &w = work[depth];
+        be.memset0(w.T2i, 4 * (deg + 1) * sizeof(cplx));                     // upper half of T2i stays zero
+        peel(h, T + h, Ts, w.T2i + h, deg + 1, q + h, depth + 1);             // step 1, :107-116
+        prod(deg, w.T2i, deg + 1, T, Ts, w.T1, 2 * deg + 1);                  // step 2, :120-127
+        peel(h, w.T1 + deg, 2 * deg + 1, w.T1i, h + 1, q, depth + 1);         // step 3, :131-140
+        if (Ti) prod(h, w.T1i, h + 1, w.T2i + h, deg + 1, Ti, Tis);           // step 4, :144-156
+    }
+    // host-pointer driver: tm (4*(deg+1)) -> q[deg]
+    int run_host(size_t deg, const std::complex<double> *tm, std::complex<double> *q)
+    {
+        int r = init(deg);
+        cplx *dT = (cplx *)be.alloc(4 * (deg + 1) * sizeof(cplx)), *dq = (cplx *)be.alloc(deg * sizeof(cplx));
+        if (r == NFT_SUCCESS && (!dT || !dq)) r = NFT_EC_NOMEM;
+        if (r == NFT_SUCCESS) {
+            be.h2d(dT, tm, 4 * (deg + 1) * sizeof(cplx));
+            peel(deg, dT, deg + 1, nullptr, 0, dq);
+            r = rc;
+        }
+        if (r == NFT_SUCCESS) {
+            int hst[4] = {0, 0, 0, 0};
+            be.d2h(q, dq, deg * sizeof(cplx));
+            be.d2h(hst, d_status, sizeof(hst));
+            r = be.sync();
+            if (r == NFT_SUCCESS && (hst[0] & 16)) r = NFT_EC_OTHER;      // :173-176
+        }
+        be.free(dT); be.free(dq);
+        destroy();
+        return r;
+    }
+};
 
 template <class BE> class NftInverseDev {
 public:
