@@ -71,8 +71,27 @@ FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 // wave shuffles of doubles (body_peel_leaf: one wave per workgroup)
 FA_DEV double fa_shfl(double v, int src) { return __shfl(v, src, 64); }
-FA_DEV double fa_shfl_up1(double v) { return __shfl_up(v, 1, 64); }
-FA_DEV double fa_shfl_down1(double v) { return __shfl_down(v, 1, 64); }
+// value of lane `src` (the same for the whole wave, a compile-time or scalar index): v_readlane, no LDS crossbar
+FA_DEV double fa_readlane(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// neighbour lanes of the whole wave by DPP (wave_shr:1 / wave_shl:1 of the gfx9 family): lane l gets lane l-1
+// (up) or l+1 (down); the end lanes keep their own value (callers overwrite them)
+FA_DEV double fa_shfl_up1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+FA_DEV double fa_shfl_down1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 // hardware reciprocals (v_rcp_f64 / v_rcp_f32): starting values, refine where accuracy matters
 FA_DEV double fa_rcp_approx(double x) { return __builtin_amdgcn_rcp(x); }
 FA_DEV float fa_rcp_approx_f32(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -144,6 +163,7 @@ FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_R
 FA_DEV double fa_rcp_approx(double x) { return 1.0 / x; }
 // the lane emulator runs no kernel that shuffles (body_peel_leaf is GPU-only): placeholders for the parser
 FA_DEV double fa_shfl(double v, int) { return v; }
+FA_DEV double fa_readlane(double v, int) { return v; }
 FA_DEV double fa_shfl_up1(double v) { return v; }
 FA_DEV double fa_shfl_down1(double v) { return v; }
 FA_DEV float fa_rcp_approx_f32(float x) { return 1.0f / x; }

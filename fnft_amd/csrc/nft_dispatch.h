@@ -101,8 +101,8 @@ struct KPeelExport {
 };
 struct KPeelLeaf {
     using Params = PeelLeafParams;
-    static constexpr int THREADS = 64;
-    static constexpr size_t lds_bytes() { return 0; }
+    static constexpr int THREADS = 192;
+    static constexpr size_t lds_bytes() { return 256 * (sizeof(cplx) + sizeof(double)); }
     static FA_DEV void body(const Params &p) { body_peel_leaf(p); }
 };
 struct KInvSolitons {

@@ -142,6 +142,16 @@ FA_DEV cplx c_sin(cplx z)
     fa_sincos(z.x, &s, &c);
     return cmake(s * cosh(z.y), c * sinh(z.y));
 }
+// 1/x where a division sits in an inner loop or on a dependent chain (Aberth sums, layer peeling): hardware reciprocal + two Newton steps (no scaling / fix-up of the IEEE division:
+// the arguments are squared distances of estimates, far from the ends of the exponent range)
+FA_DEV double aberth_rcp(double x)
+{
+    double r = fa_rcp_approx(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 FA_DEV cplx c_div(cplx a, cplx b)
 {
     // Smith's algorithm
@@ -2801,11 +2811,14 @@ FA_DEV void body_peel_export(const PeelIoParams &P)
     P.C[(long long)e * P.Cs + k] = P.src[i] * pow2i(P.W[0]);
 }
 
-// One block of d <= 256 samples peeled off by ONE wave, coefficient arrays in registers (4 consecutive indices per
-// lane), one sample per step: with Q = -kappa conj(T21(0)/T11(0)) (:158-176) the last step matrix is divided out,
-//   T1j <- scl (T1j - Q T2j),   T2j <- scl (kappa Q* T1j + T2j) / z,          scl = 1/sqrt(1 + kappa |Q|^2),
-// and the same matrix is multiplied onto the block's inverse (up to a power of z), which the caller one level up
-// needs (:144-156).  In exact arithmetic this is what the reference's recursion computes for the block.
+// One block of d <= 256 samples peeled off by one workgroup of three waves, coefficient arrays in registers (4
+// consecutive indices per lane), one sample per step: with Q = -kappa conj(T21(0)/T11(0)) (:158-176) the last step
+// matrix is divided out of the first column,
+//   T11 <- scl (T11 - Q T21),   T21 <- scl (kappa Q* T11 + T21) / z,          scl = 1/sqrt(1 + kappa |Q|^2)
+// (wave 0; the second column of T never influences the samples), and the same matrices are multiplied onto the
+// block's inverse (up to a power of z), which the caller one level up needs (:144-156): waves 1 and 2, one column
+// each, from the Q and scl that wave 0 left in LDS.  In exact arithmetic this is what the reference's recursion
+// computes for the block.
 struct PeelLeafParams {
     const cplx *T;            // four entries of d+1 coefficients at stride Ts (highest power first)
     long long Ts;
@@ -2818,98 +2831,111 @@ struct PeelLeafParams {
     int *status;              // bit 4: a reconstructed sample violates 1 + kappa |eps q|^2 > 0 (:173-176)
 };
 FA_DEV cplx fa_shfl_c(cplx v, int src) { return cmake(fa_shfl(v.x, src), fa_shfl(v.y, src)); }
+FA_DEV cplx fa_readlane_c(cplx v, int src) { return cmake(fa_readlane(v.x, src), fa_readlane(v.y, src)); }
 FA_DEV cplx fa_shfl_up_c(cplx v) { return cmake(fa_shfl_up1(v.x), fa_shfl_up1(v.y)); }
 FA_DEV cplx fa_shfl_down_c(cplx v) { return cmake(fa_shfl_down1(v.x), fa_shfl_down1(v.y)); }
 FA_DEV void body_peel_leaf(const PeelLeafParams &P)
 {
     constexpr int R = 4;
-    const int lane = FA_TID;            // 64 lanes
+    FA_LDS_DECL
+    cplx *Qs = (cplx *)FA_LDS_PTR;               // 256 step parameters Q
+    double *Ss = (double *)(Qs + 256);           // 256 scale factors
+    const int wave = FA_TID / 64, lane = FA_TID % 64;
     const int d = P.d;
-    // element K (1 <= K <= d) of every array lives in lane (K-1)/R, slot (K-1)%R; element 0 in `t0` of every lane
-    cplx t[4][R], a[4][R], t0[4];
     const cplx zero = cmake(0.0, 0.0);
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        t0[e] = P.T[(long long)e * P.Ts];
+    // element K (1 <= K <= d) of an array lives in lane (K-1)/R, slot (K-1)%R; element 0 in a register of its own
+    if (wave == 0) {
+        cplx t1[R], t2[R];
+        const cplx t10 = P.T[0], t20 = P.T[2 * P.Ts];
 #pragma unroll
         for (int s = 0; s < R; s++) {
             const int K = lane * R + s + 1;
-            t[e][s] = (K <= d) ? P.T[(long long)e * P.Ts + K] : zero;
-            a[e][s] = (K == d && (e == 0 || e == 3)) ? cmake(1.0, 0.0) : zero;   // identity: constant terms
+            t1[s] = (K <= d) ? P.T[K] : zero;
+            t2[s] = (K <= d) ? P.T[2 * P.Ts + K] : zero;
+        }
+        const int lastLane = (d - 1) / R, lastSlot = (d - 1) % R;
+        for (int step = 0; step < d; step++) {
+            cplx c11 = zero, c21 = zero;                    // constant terms T11[d], T21[d]
+#pragma unroll
+            for (int s = 0; s < R; s++)
+                if (s == lastSlot) { c11 = t1[s]; c21 = t2[s]; }
+            c11 = fa_readlane_c(c11, lastLane);
+            c21 = fa_readlane_c(c21, lastLane);
+            // Q = -kappa conj(c21 / c11) = -kappa c11 conj(c21) / |c11|^2 (reciprocal by v_rcp_f64 + two Newton steps:
+            // this division sits on the dependent chain of the block's d steps)
+            const cplx Q = (c11 * cconj(c21)) * ((double)(-P.kappa) * aberth_rcp(cnorm2(c11)));
+            if (lane == 0) Qs[step] = Q;
+            const cplx kQc = cconj(Q) * (double)P.kappa;
+            // row 1 element-wise, row 2 takes the left neighbour (division by z)
+            cplx l1 = fa_shfl_up_c(t1[R - 1]), l2 = fa_shfl_up_c(t2[R - 1]);
+            if (lane == 0) { l1 = t10; l2 = t20; }          // element 0 is only ever read in the first step
+            cplx n1[R], n2[R];
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                // without the factor scl: Q only sees the ratio T21/T11, and scl only matters for the inverse
+                n1[s] = t1[s] - Q * t2[s];
+                const cplx p1 = (s == 0) ? l1 : t1[s - 1], p2 = (s == 0) ? l2 : t2[s - 1];
+                n2[s] = kQc * p1 + p2;
+            }
+#pragma unroll
+            for (int s = 0; s < R; s++) { t1[s] = n1[s]; t2[s] = n2[s]; }
         }
     }
-    cplx a0[4] = {zero, zero, zero, zero};   // element 0 of the inverse
-    const int lastLane = (d - 1) / R, lastSlot = (d - 1) % R;
-    bool bad = false;
-    for (int step = 0; step < d; step++) {
-        // constant terms T11[d], T21[d]
-        cplx c11 = zero, c21 = zero;
-#pragma unroll
-        for (int s = 0; s < R; s++)
-            if (s == lastSlot) { c11 = t[0][s]; c21 = t[2][s]; }
-        c11 = fa_shfl_c(c11, lastLane);
-        c21 = fa_shfl_c(c21, lastLane);
-        const cplx Q = cconj(c_div(c21, c11)) * (double)(-P.kappa);
+    FA_SYNC();
+    // samples and scale factors of all steps at once (off the dependent chain of the loop above), :158-196
+    for (int step = FA_TID; step < d; step += FA_BDIM) {
+        const cplx Q = Qs[step];
         const double aQ2 = cnorm2(Q);
         const double den = 1.0 + (double)P.kappa * aQ2;
-        if (!(den > 0.0)) bad = true;
-        const double scl = 1.0 / sqrt(den);
-        if (lane == 0) {
-            cplx qv;
-            if (P.modal) qv = Q * (1.0 / P.eps_t);
-            else {
-                const double aQ = sqrt(aQ2);
-                const double f = (aQ > 0.0) ? atan(aQ) / (aQ * P.eps_t) : 1.0 / P.eps_t;   // atan|Q| e^{i arg Q} / eps
-                qv = Q * f;
-            }
-            P.q[d - 1 - step] = qv;
+        if (!(den > 0.0)) fa_atomic_or_i32(P.status, 16);
+        Ss[step] = 1.0 / sqrt(den);
+        cplx qv;
+        if (P.modal) qv = Q * (1.0 / P.eps_t);
+        else {
+            const double aQ = sqrt(aQ2);
+            const double f = (aQ > 0.0) ? atan(aQ) / (aQ * P.eps_t) : 1.0 / P.eps_t;   // atan|Q| e^{i arg Q} / eps
+            qv = Q * f;
         }
-        const cplx kQc = cconj(Q) * (double)P.kappa;
-        // T: row 1 element-wise, row 2 takes the left neighbour (division by z)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {            // columns: entries (0, 2) and (1, 3)
-            const int e1 = j, e2 = 2 + j;
-            cplx n1[R], n2[R];
-            // left neighbours of the lane's first slot
-            cplx l1 = fa_shfl_up_c(t[e1][R - 1]), l2 = fa_shfl_up_c(t[e2][R - 1]);
-            if (lane == 0) { l1 = t0[e1]; l2 = t0[e2]; }
-#pragma unroll
-            for (int s = 0; s < R; s++) {
-                n1[s] = (t[e1][s] - Q * t[e2][s]) * scl;
-                const cplx p1 = (s == 0) ? l1 : t[e1][s - 1], p2 = (s == 0) ? l2 : t[e2][s - 1];
-                n2[s] = (kQc * p1 + p2) * scl;
-            }
-#pragma unroll
-            for (int s = 0; s < R; s++) { t[e1][s] = n1[s]; t[e2][s] = n2[s]; }
-            // inverse: row 1 takes the right neighbour (multiplication by z), row 2 element-wise
-            cplx r1 = fa_shfl_down_c(a[e1][0]), r2 = fa_shfl_down_c(a[e2][0]);
-            if (lane == 63) { r1 = zero; r2 = zero; }
-            cplx m1[R], m2[R];
-            const cplx na0_1 = (a[e1][0] - Q * a[e2][0]) * scl;   // new element 0 from element 1 (lane 0, slot 0)
-            const cplx na0_2 = (kQc * a0[e1] + a0[e2]) * scl;
-#pragma unroll
-            for (int s = 0; s < R; s++) {
-                const cplx x1 = (s == R - 1) ? r1 : a[e1][s + 1], x2 = (s == R - 1) ? r2 : a[e2][s + 1];
-                m1[s] = (x1 - Q * x2) * scl;
-                m2[s] = (kQc * a[e1][s] + a[e2][s]) * scl;
-            }
-#pragma unroll
-            for (int s = 0; s < R; s++) { a[e1][s] = m1[s]; a[e2][s] = m2[s]; }
-            a0[e1] = fa_shfl_c(na0_1, 0);
-            a0[e2] = fa_shfl_c(na0_2, 0);
-        }
+        P.q[d - 1 - step] = qv;
     }
-    if (bad && lane == 0) fa_atomic_or_i32(P.status, 16);
-    if (P.Ti) {
+    FA_SYNC();
+    if (wave == 0 || P.Ti == nullptr) return;
+    // inverse, column j = wave - 1: entries (0, 2) or (1, 3); starts as the identity (constant terms)
+    const int j = wave - 1;
+    cplx a1[R], a2[R], a10 = zero, a20 = zero;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            if (lane == 0) P.Ti[(long long)e * P.Tis] = a0[e];
+    for (int s = 0; s < R; s++) {
+        const int K = lane * R + s + 1;
+        a1[s] = (K == d && j == 0) ? cmake(1.0, 0.0) : zero;
+        a2[s] = (K == d && j == 1) ? cmake(1.0, 0.0) : zero;
+    }
+    for (int step = 0; step < d; step++) {
+        const cplx Q = Qs[step];
+        const double scl = Ss[step];
+        const cplx kQc = cconj(Q) * (double)P.kappa;
+        // row 1 takes the right neighbour (multiplication by z), row 2 element-wise
+        cplx r1 = fa_shfl_down_c(a1[0]), r2 = fa_shfl_down_c(a2[0]);
+        if (lane == 63) { r1 = zero; r2 = zero; }
+        const cplx n10 = fa_readlane_c((a1[0] - Q * a2[0]) * scl, 0);   // new element 0 from element 1 (lane 0, slot 0)
+        const cplx n20 = (kQc * a10 + a20) * scl;
+        cplx m1[R], m2[R];
 #pragma unroll
-            for (int s = 0; s < R; s++) {
-                const int K = lane * R + s + 1;
-                if (K <= d) P.Ti[(long long)e * P.Tis + K] = a[e][s];
-            }
+        for (int s = 0; s < R; s++) {
+            const cplx x1 = (s == R - 1) ? r1 : a1[s + 1], x2 = (s == R - 1) ? r2 : a2[s + 1];
+            m1[s] = (x1 - Q * x2) * scl;
+            m2[s] = (kQc * a1[s] + a2[s]) * scl;
         }
+#pragma unroll
+        for (int s = 0; s < R; s++) { a1[s] = m1[s]; a2[s] = m2[s]; }
+        a10 = n10;
+        a20 = n20;
+    }
+    cplx *o1 = P.Ti + (long long)j * P.Tis, *o2 = P.Ti + (long long)(2 + j) * P.Tis;
+    if (lane == 0) { o1[0] = a10; o2[0] = a20; }
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        const int K = lane * R + s + 1;
+        if (K <= d) { o1[K] = a1[s]; o2[K] = a2[s]; }
     }
 }
 
@@ -3112,16 +3138,6 @@ FA_DEV cplx c_powi(cplx x, long long e)
         x = x * x;
         e >>= 1;
     }
-    return r;
-}
-
-// 1/x for the Aberth sums: hardware reciprocal + two Newton steps (no scaling / fix-up of the IEEE division:
-// the arguments are squared distances of estimates, far from the ends of the exponent range)
-FA_DEV double aberth_rcp(double x)
-{
-    double r = fa_rcp_approx(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
 
