@@ -263,9 +263,10 @@ FNFT_INT fnft__poly_fmult_two_polys2x2(const FNFT_UINT deg, FNFT_COMPLEX const *
 
 /* include/private/fnft__nse_finvscatter.h (src/private/fnft__nse_finvscatter.c:234-366): fast inverse scattering by
  * layer peeling -- the D = deg samples q behind a transfer matrix [T11|T12|T21|T22] (each deg+1, highest power first,
- * as fnft__nse_fscatter returns it with W_ptr = NULL), D a power of two, 2SPLIT2_MODAL or 2SPLIT2A.  Host buffers;
- * the degree >= 512 products run on the GPU.  FNFT_EC_OTHER if a reconstructed sample violates |eps_t q| < 1
- * (defocusing) or D is not a power of two. */
+ * as fnft__nse_fscatter returns it with W_ptr = NULL), D a power of two, 2SPLIT2_MODAL or 2SPLIT2A.  Host buffers in
+ * and out; in between everything is on the GPU: blocks of 256 samples by a leaf kernel, the 2x2 polynomial products
+ * above that by the tree's pair kernels, no synchronisation inside the recursion.  FNFT_EC_OTHER if a reconstructed
+ * sample violates |eps_t q| < 1 (defocusing) or D is not a power of two. */
 FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer_matrix, FNFT_COMPLEX *const q,
                                const FNFT_REAL eps_t, const FNFT_INT kappa, const fnft_nse_discretization_t discretization);
 
