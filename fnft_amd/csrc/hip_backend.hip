@@ -551,10 +551,26 @@ FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer
     if (!modal && discretization != fnft_nse_discretization_2SPLIT2A) return FNFT_EC_INVALID_ARGUMENT;
     if (current_device() < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
-    HipBackend be;
-    NftLayerPeelingDev<HipBackend> lp(be, eps_t, (int)kappa, modal ? 1 : 0);
-    const int rc = lp.run_host(deg, transfer_matrix, q);
-    if (be.failed) return FNFT_EC_OTHER;
+    // one resident peeler per device: its pair-product plans (one per degree) and work arrays are reused by later
+    // calls; sizes beyond 2^18 samples release everything again (workspace footprint)
+    struct Peeler {
+        HipBackend be;
+        NftLayerPeelingDev<HipBackend> lp;
+        Peeler() : lp(be, 1.0, 1, 1) {}
+    };
+    static std::map<int, Peeler *> peelers;
+    const int dev = current_device();
+    Peeler *&pp = peelers[dev];
+    if (!pp) pp = new (std::nothrow) Peeler();
+    if (!pp) return FNFT_EC_NOMEM;
+    pp->be.failed = false;
+    pp->lp.eps_t = eps_t;
+    pp->lp.kappa = (int)kappa;
+    pp->lp.modal = modal ? 1 : 0;
+    const int rc = pp->lp.run_host(deg, transfer_matrix, q);
+    const bool failed = pp->be.failed;
+    if (failed || rc != FNFT_SUCCESS || deg > ((size_t)1 << 18)) pp->lp.destroy();
+    if (failed) return FNFT_EC_OTHER;
     return rc;
 }
 

@@ -93,12 +93,6 @@ struct KPeelImport {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_peel_import(p); }
 };
-struct KPeelExport {
-    using Params = PeelIoParams;
-    static constexpr int THREADS = 256;
-    static constexpr size_t lds_bytes() { return 0; }
-    static FA_DEV void body(const Params &p) { body_peel_export(p); }
-};
 struct KPeelLeaf {
     using Params = PeelLeafParams;
     static constexpr int THREADS = 192;

@@ -1909,6 +1909,8 @@ struct ExportParams {
     int batch;
     int ne;             // 4 general, 2 symmetric
     int kappa;
+    long long out_stride = 0;   // != 0 (batch 1): entry e goes to out[e*out_stride + k] instead of out[e*(deg+1) + k]
+    const int *W = nullptr;     // != NULL: values are multiplied by 2^W[0] (un-normalised result)
 };
 // coefficient k (highest power first, k <= deg) of stored plane s of signal b.  General form:
 // identity padding z^deg0*I leaves TRAILING zeros, index k.  Symmetric form: padding with the
@@ -1942,7 +1944,9 @@ FA_DEV void body_export_tm(const ExportParams &E)
         val = cconj(stored_coef(E.body, E.tail, E.plane, E.deg_tot, E.deg, E.batch, 2, 1, b, E.deg - k))
               * (double)(-E.kappa);
     }
-    E.out[gid] = val * sc;
+    const double sw = E.W ? sc * pow2i(E.W[0]) : sc;
+    if (E.out_stride != 0) E.out[(long long)e * E.out_stride + k] = val * sw;
+    else E.out[gid] = val * sw;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2774,7 +2778,7 @@ FA_DEV void body_inv_op(const InvOpParams &P)
 
 // ---- layer peeling on the device (src/private/fnft__nse_finvscatter.c:66-232) ------------------------------------
 // Two factors of a 2x2 polynomial product from arbitrary strided device arrays into level 0 of a plan with n = 2
-// matrices of degree d (body/tail layout), and the product back out, multiplied by 2^W (un-normalised).
+// matrices of degree d (body/tail layout); the product comes back out through body_export_tm (strided, times 2^W).
 struct PeelIoParams {
     const cplx *A, *B;        // four entries of d+1 coefficients each, highest power first
     long long As, Bs;         // entry strides
@@ -2782,10 +2786,6 @@ struct PeelIoParams {
     cplx *body, *tail;        // import: level 0 of the plan (plane = 2*d)
     double *scale;
     int *wexp;
-    const cplx *src;          // export: the plan's result layout, four entries of dout+1 = 2d+1
-    const int *W;             // export: exponent taken out by the plan
-    cplx *C;                  // export: four entries at stride Cs
-    long long Cs;
 };
 FA_DEV void body_peel_import(const PeelIoParams &P)
 {
@@ -2801,16 +2801,6 @@ FA_DEV void body_peel_import(const PeelIoParams &P)
     else P.tail[e * 2 + m] = v;
     if (i < 2) { P.scale[i] = 1.0; P.wexp[i] = 0; }
 }
-FA_DEV void body_peel_export(const PeelIoParams &P)
-{
-    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
-    const long long w = 2 * P.d + 1;
-    if (i >= 4 * w) return;
-    const int e = (int)(i / w);
-    const long long k = i % w;
-    P.C[(long long)e * P.Cs + k] = P.src[i] * pow2i(P.W[0]);
-}
-
 // One block of d <= 256 samples peeled off by one workgroup of three waves, coefficient arrays in registers (4
 // consecutive indices per lane), one sample per step: with Q = -kappa conj(T21(0)/T11(0)) (:158-176) the last step
 // matrix is divided out of the first column,

@@ -53,21 +53,34 @@ public:
         plans.clear();
         for (auto &w : work) { be.free(w.T2i); be.free(w.T1); be.free(w.T1i); }
         work.clear();
+        work_deg = 0;
         be.free(d_status);
         d_status = nullptr;
     }
+    // status word, work arrays for a transfer matrix of degree deg (kept and reused by later calls of the same or a
+    // smaller size: depth 0 is always the largest)
+    size_t work_deg = 0;
     int init(size_t deg)
     {
-        d_status = (int *)be.alloc(4 * sizeof(int));
-        if (!d_status) return NFT_EC_NOMEM;
+        rc = NFT_SUCCESS;
+        if (!d_status) {
+            d_status = (int *)be.alloc(4 * sizeof(int));
+            if (!d_status) return NFT_EC_NOMEM;
+        }
         be.memset0(d_status, 4 * sizeof(int));
-        for (size_t d = deg; d > kLeaf; d /= 2) {
-            Work w;
-            w.T2i = (cplx *)be.alloc(4 * (d + 1) * sizeof(cplx));
-            w.T1 = (cplx *)be.alloc(4 * (2 * d + 1) * sizeof(cplx));
-            w.T1i = (cplx *)be.alloc(4 * (d / 2 + 1) * sizeof(cplx));
-            work.push_back(w);
-            if (!w.T2i || !w.T1 || !w.T1i) return NFT_EC_NOMEM;
+        if (deg > work_deg) {
+            for (auto &w : work) { be.free(w.T2i); be.free(w.T1); be.free(w.T1i); }
+            work.clear();
+            work_deg = 0;
+            for (size_t d = deg; d > kLeaf; d /= 2) {
+                Work w;
+                w.T2i = (cplx *)be.alloc(4 * (d + 1) * sizeof(cplx));
+                w.T1 = (cplx *)be.alloc(4 * (2 * d + 1) * sizeof(cplx));
+                w.T1i = (cplx *)be.alloc(4 * (d / 2 + 1) * sizeof(cplx));
+                work.push_back(w);
+                if (!w.T2i || !w.T1 || !w.T1i) return NFT_EC_NOMEM;
+            }
+            work_deg = deg;
         }
         return NFT_SUCCESS;
     }
@@ -99,9 +112,7 @@ public:
         pl->start_d = deg;
         const int r = pl->run_tree();
         if (r != NFT_SUCCESS) { rc = r; return; }
-        pl->export_tm();
-        P.src = pl->tm_out; P.W = pl->wexp[pl->cur]; P.C = C; P.Cs = (long long)Cs;
-        be.template run<KPeelExport>((int)((4 * (2 * deg + 1) + 255) / 256), 1, P);
+        pl->export_tm(C, Cs, true);     // result layout, un-normalised, straight into the caller's strided array
     }
     // T: four entries of deg+1 coefficients at stride Ts; Ti (may be NULL): the inverse up to a power of z, four
     // entries of deg+1 at stride Tis; q: deg samples.  All device pointers.
@@ -117,7 +128,10 @@ public:
             return;
         }
         const size_t h = deg / 2;
-        Work &w = work[depth];
+        size_t slot = 0;                                                      // work[0] serves degree work_deg
+        for (size_t d = work_deg; d > deg; d /= 2) slot++;
+        (void)depth;
+        Work &w = work[slot];
         be.memset0(w.T2i, 4 * (deg + 1) * sizeof(cplx));                     // upper half of T2i stays zero
         peel(h, T + h, Ts, w.T2i + h, deg + 1, q + h, depth + 1);             // step 1, :107-116
         prod(deg, w.T2i, deg + 1, T, Ts, w.T1, 2 * deg + 1);                  // step 2, :120-127
@@ -143,8 +157,7 @@ public:
             if (r == NFT_SUCCESS && (hst[0] & 16)) r = NFT_EC_OTHER;      // :173-176
         }
         be.free(dT); be.free(dq);
-        destroy();
-        return r;
+        return r;      // plans and work arrays stay for the next call (destroy() releases them)
     }
 };
 

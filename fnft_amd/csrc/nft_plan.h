@@ -574,11 +574,14 @@ public:
     }
 
     // ---- result in the reference layout (fnft__poly_fmult.c:522-538) ---------------------------
-    void export_tm()
+    // dst / stride / unscale: the result straight into a caller's strided device array, times 2^W (layer peeling)
+    void export_tm(cplx *dst = nullptr, size_t stride = 0, bool unscale = false)
     {
         ExportParams E;
         E.body = body[cur]; E.tail = tail[cur]; E.scale = scale[cur];
-        E.out = tm_out;
+        E.out = dst ? dst : tm_out;
+        E.out_stride = dst ? (long long)stride : 0;
+        E.W = unscale ? wexp[cur] : nullptr;
         E.plane = plane;
         E.deg_tot = (long long)(Dpad * (size_t)deg0);
         E.deg = (long long)res_deg;
