@@ -189,6 +189,86 @@ def bench_cfg4(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+def bench_inverse(args, rank, world, local_rank):
+    """fnft_nsev_inverse through the host-pointer drop-in: b(xi) of a sech pulse below the soliton
+    threshold -> q (the reference's b_of_xi test at D = 2^log2D, default 2^16), 2SPLIT2_MODAL, M = D.  One call per step;
+    every rank inverts its own spectrum (weak scaling, nothing to gather but D samples)."""
+    import torch
+    import torch.distributed as dist
+    from fnft_amd import capi
+    import signals as S
+
+    capi.load()
+    log2D = args.log2D if args.log2D != 20 else 16
+    D = 1 << log2D
+    T = [-25.0, 25.0]
+    A, t0 = 0.45 - 0.001 * rank, 1.2
+    rc, XI = capi.nsev_inverse_XI(D, T, D, "2SPLIT2_MODAL")
+    xi = XI[0] + (XI[1] - XI[0]) / (D - 1) * np.arange(D)
+    with np.errstate(over="ignore"):
+        cs0 = 1j * np.exp(-2j * xi * t0) * np.sin(np.pi * A) / np.cosh(np.pi * xi)
+    exact = 1j * A / np.cosh(S.tgrid(T, D) - t0)
+    opts = {"discretization": "2SPLIT2_MODAL", "contspec_type": "B_OF_XI"}
+
+    def call():
+        rc, q = capi.fnft_nsev_inverse(D, cs0.copy(), XI, None, None, D, T, 1, opts)
+        if rc != 0:
+            raise RuntimeError("fnft_nsev_inverse rc=%d: %s" % (rc, capi.last_error()))
+        return q
+    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+    for _ in range(warm):
+        q = call()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0w = time.perf_counter()
+    for _ in range(steps):
+        q = call()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall_ms = (time.perf_counter() - t0w) * 1e3
+    tt = torch.tensor([wall_ms], dtype=torch.float64, device="cpu" if (world == 1 or args.rehearse_gloo) else "cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ms_per_step = float(tt.item()) / steps
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import inverse as INV
+            Dc = min(D, 1 << 14)            # bounded sample: the numpy restatement needs 0.6 s at 2^14, 2.5 s at 2^16
+            rcx, XIc = capi.nsev_inverse_XI(Dc, T, Dc, "2SPLIT2_MODAL")
+            xic = XIc[0] + (XIc[1] - XIc[0]) / (Dc - 1) * np.arange(Dc)
+            with np.errstate(over="ignore"):
+                csc = 1j * np.exp(-2j * xic * t0) * np.sin(np.pi * A) / np.cosh(np.pi * xic)
+            tc0 = time.perf_counter()
+            nrep = 8
+            for _ in range(nrep):
+                rco, qo = INV.fnft_nsev_inverse(Dc, csc.copy(), XIc, None, None, Dc, T, 1, opts)
+            tc = time.perf_counter() - tc0
+            rcg, qg = capi.fnft_nsev_inverse(Dc, csc.copy(), XIc, None, None, Dc, T, 1, opts)
+            cpu = {"value": round(nrep * Dc / tc / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                   "sample": "%d calls, D=M=2^%d, b(xi) -> q, oracle/inverse.py (numpy, one thread), %.1f s"
+                             % (nrep, int(math.log2(Dc)), tc),
+                   "gpu_vs_cpu_rel_l1": {"q": float(S.rel_err(qg, qo))}}
+        line = {
+            "metric": "Msamples/s fnft_nsev_inverse b(xi) -> q (D=2^%d fp64)" % log2D,
+            "value": round(world * D / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Msamples/s", "n_gpus": world,
+            "steps": steps, "warmup": warm, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "fnft_nsev_inverse D=M=2^%d, contspec_type B_OF_XI (spectral factorization at "
+                                   "oversampling 8 + layer peeling), 2SPLIT2_MODAL, host-pointer drop-in call, 1 spectrum per GPU"
+                                   % log2D, "gather": "n/a"},
+            "roofline": {"bound": "hbm", "kernel": "layer peeling (leaf kernel + pair products); latency-bound chain, see DESIGN.md 5",
+                         "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                         "rel_err_vs_exact_signal": float(S.rel_err(q, exact))},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,7 +276,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2D", type=int, default=20)
     ap.add_argument("--disc", default="2SPLIT2_MODAL")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5", "inverse"), default="cfg2",
                     help="cfg2: one signal D=M=2^20 per GPU (headline); cfg3: BASELINE.json configs[2], "
                          "64 of the 512 signals D=M=2^16 per GPU; cfg4: configs[3], contspec + bound states at "
                          "D=M=2^20 through the drop-in fnft_nsev (host pointers, default options); cfg5: configs[4], "
@@ -235,6 +315,8 @@ def main():
 
     if args.workload == "cfg4":
         return bench_cfg4(args, rank, world, local_rank)
+    if args.workload == "inverse":
+        return bench_inverse(args, rank, world, local_rank)
     if args.no_gather:
         args.gather = "none"
     cfg3 = args.workload == "cfg3"
