@@ -115,6 +115,9 @@ static FNFT_UINT nse_degree(fnft_nse_discretization_t d)
     }
 }
 
+/* shared with fnft_nsev_inverse_host.c */
+FNFT_UINT fnft_amd__nse_degree(fnft_nse_discretization_t d) { return nse_degree(d); }
+
 /* src/fnft_nsev.c:51-57 */
 FNFT_UINT fnft_nsev_max_K(const FNFT_UINT D, fnft_nsev_opts_t const *const opts)
 {

@@ -13,6 +13,7 @@
 #include "../../include/fnft_amd.h"
 
 FNFT_INT fnft_amd__raise(FNFT_INT ec, const char *func, int line, const char *msg);   /* fnft_nsev_host.c */
+FNFT_UINT fnft_amd__nse_degree(fnft_nse_discretization_t d);
 void fnft_amd__warn(const char *msg, const char *func, int line);
 #define E_INVALID_ARGUMENT(name) fnft_amd__raise(FNFT_EC_INVALID_ARGUMENT, __func__, __LINE__, "Invalid argument " #name ".")
 #define E_SANITY_CHECK_FAILED(msg) fnft_amd__raise(FNFT_EC_SANITY_CHECK_FAILED, __func__, __LINE__, "Sanity check failed (" #msg ").")
@@ -51,15 +52,13 @@ FNFT_INT fnft_nsev_inverse_XI(const FNFT_UINT D, FNFT_REAL const *const T, const
         return E_INVALID_ARGUMENT(XI);
     if (T == NULL || !(T[0] < T[1]))
         return E_INVALID_ARGUMENT(T);
-    FNFT_REAL degree1step;
-    switch (discretization) {   /* the schemes with a polynomial degree of 1 per step and the slow ones map alike */
-    case fnft_nse_discretization_2SPLIT2_MODAL:
-    case fnft_nse_discretization_2SPLIT2A:
-        degree1step = 1.0;
-        break;
-    default:
+    /* degree of one step times the upsampling factor, fnft__akns_discretization.c:225-240; unknown (slow)
+     * discretizations have degree 0 there and fail the same way */
+    FNFT_REAL degree1step = (FNFT_REAL)fnft_amd__nse_degree(discretization);
+    if (degree1step == 0)
         return E_SUBROUTINE(FNFT_EC_INVALID_ARGUMENT);
-    }
+    if (discretization == fnft_nse_discretization_4SPLIT4A || discretization == fnft_nse_discretization_4SPLIT4B)
+        degree1step *= 2.0;
     const FNFT_REAL eps_t = (T[1] - T[0]) / (D - 1);
     const double complex z0 = cexp(2.0 * 3.14159265358979323846 * I * (double)(M / 2 + 1) / (double)M);
     const double complex z1 = -1.0;
