@@ -161,9 +161,16 @@ struct KExportTm {
 #ifndef FA_PAIR_R_SYM
 #define FA_PAIR_R_SYM 8
 #endif
+#ifndef FA_PAIR_R_GEN2K
+#define FA_PAIR_R_GEN2K 8   // N = 2048, general form
+#endif
+#ifndef FA_PAIR_R_GEN
+#define FA_PAIR_R_GEN 4   // general form at 4 points per lane: 170-200 VGPRs, 2 waves/SIMD (8: 320-416 VGPRs at 1 wave/SIMD;
+#endif                    // fnft_kdvv cfg 5: the eight single-launch levels 2.66 -> 2.19 ms)
 template <int N, int NE = 4> struct PairCfg {
-    // points per lane: 8; (experiment knob: the symmetric form can run with 4 for N <= 1024)
-    static constexpr int R = (NE == 2 && N <= 1024 && N >= 16) ? FA_PAIR_R_SYM : 8;
+    // points per lane: 8; (experiment knobs: 4 for N <= 1024, symmetric and general form separately)
+    static constexpr int R = (N >= 16 && N <= 1024) ? (NE == 2 ? FA_PAIR_R_SYM : FA_PAIR_R_GEN)
+                             : ((N == 2048 && NE == 4) ? FA_PAIR_R_GEN2K : 8);
     static constexpr int THREADS = (N / R > 256) ? N / R : 256;
     static constexpr int B = THREADS / (N / R);
     static constexpr bool DB = (N <= 2048);  // N = 4096: one 64 KB buffer
@@ -175,7 +182,7 @@ template <int N, int NE> struct KPairFft {
     // general form: 1 wave/SIMD for 256-lane groups (no scratch spills at ~400 registers); the
     // 512-lane N = 4096 group needs 2 waves/SIMD to be resident at all.  The symmetric form
     // holds half the spectra and fits 2 waves/SIMD.
-    static constexpr int MIN_WAVES = (C::THREADS > 256 || NE == 2) ? (C::R == 4 ? 4 : 2) : 1;
+    static constexpr int MIN_WAVES = (C::THREADS > 256 || NE == 2) ? (C::R == 4 ? 4 : 2) : (C::R == 4 ? 2 : 1);
     static constexpr size_t lds_bytes()
     {
         return ((N > C::R && C::DB) ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx)
