@@ -24,7 +24,7 @@ template <int DEG> struct KCoeffs {
 struct KCoeffsProg {
     using Params = CoeffProgParams;
     static constexpr int THREADS = 64;
-    static constexpr size_t lds_bytes() { return 0; }
+    static constexpr size_t lds_bytes() { return (size_t)(24 + 16) * 64 * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_coeffs_prog(p); }
 };
 struct KResamplePhase {
@@ -162,7 +162,7 @@ struct KExportTm {
 #define FA_PAIR_R_SYM 8
 #endif
 #ifndef FA_PAIR_R_GEN2K
-#define FA_PAIR_R_GEN2K 8   // N = 2048, general form
+#define FA_PAIR_R_GEN2K 4   // N = 2048, general form: 512 lanes, 210 VGPRs, 2 waves/SIMD (8: 382 + 126 registers at 1)
 #endif
 #ifndef FA_PAIR_R_GEN
 #define FA_PAIR_R_GEN 4   // general form at 4 points per lane: 170-200 VGPRs, 2 waves/SIMD (8: 320-416 VGPRs at 1 wave/SIMD;
@@ -182,7 +182,7 @@ template <int N, int NE> struct KPairFft {
     // general form: 1 wave/SIMD for 256-lane groups (no scratch spills at ~400 registers); the
     // 512-lane N = 4096 group needs 2 waves/SIMD to be resident at all.  The symmetric form
     // holds half the spectra and fits 2 waves/SIMD.
-    static constexpr int MIN_WAVES = (C::THREADS > 256 || NE == 2) ? (C::R == 4 ? 4 : 2) : (C::R == 4 ? 2 : 1);
+    static constexpr int MIN_WAVES = (NE == 4 && C::R == 4) ? 2 : ((C::THREADS > 256 || NE == 2) ? (C::R == 4 ? 4 : 2) : 1);
     static constexpr size_t lds_bytes()
     {
         return ((N > C::R && C::DB) ? (size_t)2 : (size_t)1) * N * C::B * sizeof(cplx)

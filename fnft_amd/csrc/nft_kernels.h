@@ -361,56 +361,78 @@ struct CoeffProgParams {
     int nB, maxf;
 };
 
+// One lane per sample.  The step-matrix elements (up to 24 per sample) are indexed by the program, so they live in
+// LDS ([element][lane]: the program is the same for every lane, a read is one contiguous line) instead of a
+// dynamically indexed register array (= scratch memory); the coefficients are collected in LDS too, 16 per sample
+// and round, and leave as runs of 256 bytes (a lane's own coefficients of one power are deg*16 bytes apart).
 FA_DEV void body_coeffs_prog(const CoeffProgParams &Q)
 {
+    FA_LDS_DECL
+    cplx *el = (cplx *)FA_LDS_PTR;                       // 24 x 64
+    cplx *stage = el + 24 * 64;                          // 16 x 64: one staging round
     const CoeffParams &P = Q.c;
-    const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
+    const int lane = FA_TID;                             // 64 lanes
+    const long long gid0 = (long long)FA_BID * FA_BDIM;
+    const long long gid = gid0 + lane;
     const long long n = (long long)P.batch * P.Dpad;
-    if (gid >= n) return;
-    const int b = (int)(gid / P.Dpad), j = (int)(gid % P.Dpad);
+    const bool act = gid < n;
+    const int b = act ? (int)(gid / P.Dpad) : 0, j = act ? (int)(gid % P.Dpad) : 0;
     const int deg = P.deg;
     const bool pad = j >= P.D;
-    cplx el[24];
-    if (!pad) {
+    if (act && !pad) {
         const size_t src = (size_t)b * P.D + (size_t)(P.D - 1 - j);
         const cplx q = P.q[src];
         const cplx r = P.r ? P.r[src] : (P.kappa == 1 ? cmake(-q.x, q.y) : cmake(q.x, -q.y));
         for (int i = 0; i < Q.nB; i++) {
             const StepExp e = zero_freq_step(P.eps_t * Q.bfrac[i], q, r);
-            el[3 * i] = e.c;
-            el[3 * i + 1] = e.qs;
-            el[3 * i + 2] = e.rs;
+            el[(3 * i) * 64 + lane] = e.c;
+            el[(3 * i + 1) * 64 + lane] = e.qs;
+            el[(3 * i + 2) * 64 + lane] = e.rs;
         }
     }
+    const long long nact = (n - gid0 < 64) ? n - gid0 : 64;   // samples of this workgroup
+    constexpr int CH = 16;                                    // coefficients per staging round
     for (int e = 0; e < 4; e++) {
         if (P.ne == 2 && (e & 1)) continue;
         const int s = (P.ne == 2) ? (e >> 1) : e;
-        cplx *body = P.body + (size_t)s * P.plane + (size_t)gid * deg;
-        for (int k = 0; k <= deg; k++) {
-            cplx acc = cmake(0.0, 0.0);
-            if (pad) {
-                // z^deg * I in the general form, diag(1, z^deg) in the symmetric form (body_coeffs)
-                const bool one = (P.ne == 4) ? ((e == 0 || e == 3) && k == 0)
-                                             : ((e == 0 && k == deg) || (e == 3 && k == 0));
-                if (one) acc = cmake(1.0, 0.0);
-            } else {
-                const int t = e * (deg + 1) + k;
-                for (int m = Q.tgt_ptr[t]; m < Q.tgt_ptr[t + 1]; m++) {
-                    cplx prod = cmake(Q.mw[m], 0.0);
-                    for (int f = 0; f < Q.maxf; f++) {
-                        const int id = Q.mfac[(size_t)m * Q.maxf + f];
-                        if (id == 255) break;
-                        prod = prod * el[id];
+        cplx *body = P.body + (size_t)s * P.plane + (size_t)gid0 * deg;
+        for (int k0 = 0; k0 <= deg; k0 += CH) {
+            for (int k = k0; k < k0 + CH && k <= deg; k++) {
+                cplx acc = cmake(0.0, 0.0);
+                if (pad) {
+                    // z^deg * I in the general form, diag(1, z^deg) in the symmetric form (body_coeffs)
+                    const bool one = (P.ne == 4) ? ((e == 0 || e == 3) && k == 0)
+                                                 : ((e == 0 && k == deg) || (e == 3 && k == 0));
+                    if (one) acc = cmake(1.0, 0.0);
+                } else if (act) {
+                    const int t = e * (deg + 1) + k;
+                    for (int m = Q.tgt_ptr[t]; m < Q.tgt_ptr[t + 1]; m++) {
+                        cplx prod = cmake(Q.mw[m], 0.0);
+                        for (int f = 0; f < Q.maxf; f++) {
+                            const int id = Q.mfac[(size_t)m * Q.maxf + f];
+                            if (id == 255) break;
+                            prod = prod * el[id * 64 + lane];
+                        }
+                        acc = acc + prod;
                     }
-                    acc = acc + prod;
                 }
+                if (k < deg) stage[lane * CH + (k - k0)] = acc;
+                else if (act) P.tail[(size_t)s * n + gid] = acc;
             }
-            if (k < deg) body[k] = acc;
-            else P.tail[(size_t)s * n + gid] = acc;
+            FA_SYNC();
+            const int cw = (deg - k0 < CH) ? deg - k0 : CH;   // body coefficients of this round (the last one is the tail)
+            for (long long i = lane; i < nact * cw; i += 64) {
+                const long long smp = i / cw;
+                const int kk = (int)(i % cw);
+                body[smp * deg + k0 + kk] = stage[smp * CH + kk];
+            }
+            FA_SYNC();
         }
     }
-    P.scale[gid] = 1.0;
-    P.wexp[gid] = 0;
+    if (act) {
+        P.scale[gid] = 1.0;
+        P.wexp[gid] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
