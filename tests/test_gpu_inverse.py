@@ -135,9 +135,11 @@ def test_multisoliton_cdt(capi, INV, dstype):
     run(capi, IC.multisoliton_cdt(dstype), INV, 1e-12)
 
 
-def test_full_size_round_trip(capi):
-    """D = 2^18: contspec of a sech pulse by the forward transform, back by the inverse (REFL_COEFF method, M = 2D)."""
-    D = 1 << 18
+@pytest.mark.parametrize("log2D", (18, 20))
+def test_full_size_round_trip(capi, log2D):
+    """D = 2^18, 2^20: contspec of a sech pulse by the forward transform, back by the inverse (REFL_COEFF method,
+    M = 2D)."""
+    D = 1 << log2D
     T = [-32.0, 32.0]
     t = S.tgrid(T, D)
     q0 = 0.4 / np.cosh(t) * np.exp(-1j * t)
