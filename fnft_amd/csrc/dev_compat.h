@@ -69,6 +69,11 @@ FA_DEV unsigned fa_slots_max_u32(const unsigned *p)
     return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
 }
 FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
+// a counter in LDS that one wave advances and other waves of the workgroup watch (body_peel_leaf): release store /
+// acquire load at workgroup scope, so what the writer stored before the counter is visible to who sees the counter
+FA_DEV void fa_lds_publish(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+FA_DEV int fa_lds_observe(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+FA_DEV void fa_nap() { __builtin_amdgcn_s_sleep(2); }   // ~128 clocks off the issue slots while polling
 // wave shuffles of doubles (body_peel_leaf: one wave per workgroup)
 FA_DEV double fa_shfl(double v, int src) { return __shfl(v, src, 64); }
 // value of lane `src` (the same for the whole wave, a compile-time or scalar index): v_readlane, no LDS crossbar
@@ -163,6 +168,9 @@ FA_DEV void fa_atomic_or_i32(int *p, int v) { __atomic_fetch_or(p, v, __ATOMIC_R
 FA_DEV double fa_rcp_approx(double x) { return 1.0 / x; }
 // the lane emulator runs no kernel that shuffles (body_peel_leaf is GPU-only): placeholders for the parser
 FA_DEV double fa_shfl(double v, int) { return v; }
+FA_DEV void fa_lds_publish(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+FA_DEV int fa_lds_observe(const int *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+FA_DEV void fa_nap() {}
 FA_DEV double fa_readlane(double v, int) { return v; }
 FA_DEV double fa_shfl_up1(double v) { return v; }
 FA_DEV double fa_shfl_down1(double v) { return v; }

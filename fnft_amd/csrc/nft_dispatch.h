@@ -96,7 +96,7 @@ struct KPeelImport {
 struct KPeelLeaf {
     using Params = PeelLeafParams;
     static constexpr int THREADS = 192;
-    static constexpr size_t lds_bytes() { return 256 * (sizeof(cplx) + sizeof(double)); }
+    static constexpr size_t lds_bytes() { return 256 * sizeof(cplx) + 64; }
     static FA_DEV void body(const Params &p) { body_peel_leaf(p); }
 };
 struct KInvSolitons {

@@ -2829,8 +2829,9 @@ FA_DEV void body_peel_import(const PeelIoParams &P)
 //   T11 <- scl (T11 - Q T21),   T21 <- scl (kappa Q* T11 + T21) / z,          scl = 1/sqrt(1 + kappa |Q|^2)
 // (wave 0; the second column of T never influences the samples), and the same matrices are multiplied onto the
 // block's inverse (up to a power of z), which the caller one level up needs (:144-156): waves 1 and 2, one column
-// each, from the Q and scl that wave 0 left in LDS.  In exact arithmetic this is what the reference's recursion
-// computes for the block.
+// each, one step behind wave 0 (they take every Q from LDS as soon as wave 0 has published it; the scalar factors scl
+// of all steps are multiplied on at the end).  In exact arithmetic this is what the reference's recursion computes
+// for the block.
 struct PeelLeafParams {
     const cplx *T;            // four entries of d+1 coefficients at stride Ts (highest power first)
     long long Ts;
@@ -2840,7 +2841,7 @@ struct PeelLeafParams {
     cplx *q;                  // d samples
     double eps_t;
     int kappa, modal;
-    int *status;              // bit 4: a reconstructed sample violates 1 + kappa |eps q|^2 > 0 (:173-176)
+    int *status;              // bit 4: a reconstructed sample violates 1 + kappa |eps q|^2 > 0 (:173-176); bit 5: internal
 };
 FA_DEV cplx fa_shfl_c(cplx v, int src) { return cmake(fa_shfl(v.x, src), fa_shfl(v.y, src)); }
 FA_DEV cplx fa_readlane_c(cplx v, int src) { return cmake(fa_readlane(v.x, src), fa_readlane(v.y, src)); }
@@ -2851,10 +2852,13 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
     constexpr int R = 4;
     FA_LDS_DECL
     cplx *Qs = (cplx *)FA_LDS_PTR;               // 256 step parameters Q
-    double *Ss = (double *)(Qs + 256);           // 256 scale factors
+    double *Stot = (double *)(Qs + 256);         // product of the 256 scale factors
+    int *ready = (int *)(Stot + 1);              // number of steps wave 0 has published
     const int wave = FA_TID / 64, lane = FA_TID % 64;
     const int d = P.d;
     const cplx zero = cmake(0.0, 0.0);
+    if (FA_TID == 0) fa_lds_publish(ready, 0);
+    FA_SYNC();
     // element K (1 <= K <= d) of an array lives in lane (K-1)/R, slot (K-1)%R; element 0 in a register of its own
     if (wave == 0) {
         cplx t1[R], t2[R];
@@ -2876,15 +2880,18 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
             // Q = -kappa conj(c21 / c11) = -kappa c11 conj(c21) / |c11|^2 (reciprocal by v_rcp_f64 + two Newton steps:
             // this division sits on the dependent chain of the block's d steps)
             const cplx Q = (c11 * cconj(c21)) * ((double)(-P.kappa) * aberth_rcp(cnorm2(c11)));
-            if (lane == 0) Qs[step] = Q;
+            if (lane == 0) {
+                Qs[step] = Q;
+                fa_lds_publish(ready, step + 1);            // the inverse's waves follow one step behind
+            }
             const cplx kQc = cconj(Q) * (double)P.kappa;
-            // row 1 element-wise, row 2 takes the left neighbour (division by z)
+            // row 1 element-wise, row 2 takes the left neighbour (division by z); without the factor scl: Q only
+            // sees the ratio T21/T11, and the scale factors are multiplied onto the inverse at the end
             cplx l1 = fa_shfl_up_c(t1[R - 1]), l2 = fa_shfl_up_c(t2[R - 1]);
             if (lane == 0) { l1 = t10; l2 = t20; }          // element 0 is only ever read in the first step
             cplx n1[R], n2[R];
 #pragma unroll
             for (int s = 0; s < R; s++) {
-                // without the factor scl: Q only sees the ratio T21/T11, and scl only matters for the inverse
                 n1[s] = t1[s] - Q * t2[s];
                 const cplx p1 = (s == 0) ? l1 : t1[s - 1], p2 = (s == 0) ? l2 : t2[s - 1];
                 n2[s] = kQc * p1 + p2;
@@ -2892,27 +2899,31 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
 #pragma unroll
             for (int s = 0; s < R; s++) { t1[s] = n1[s]; t2[s] = n2[s]; }
         }
-    }
-    FA_SYNC();
-    // samples and scale factors of all steps at once (off the dependent chain of the loop above), :158-196
-    for (int step = FA_TID; step < d; step += FA_BDIM) {
-        const cplx Q = Qs[step];
-        const double aQ2 = cnorm2(Q);
-        const double den = 1.0 + (double)P.kappa * aQ2;
-        if (!(den > 0.0)) fa_atomic_or_i32(P.status, 16);
-        Ss[step] = 1.0 / sqrt(den);
-        cplx qv;
-        if (P.modal) qv = Q * (1.0 / P.eps_t);
-        else {
-            const double aQ = sqrt(aQ2);
-            const double f = (aQ > 0.0) ? atan(aQ) / (aQ * P.eps_t) : 1.0 / P.eps_t;   // atan|Q| e^{i arg Q} / eps
-            qv = Q * f;
+        // samples and the product of the scale factors, all steps at once (off the dependent chain), :158-196
+        double prod = 1.0;
+        for (int step = lane; step < d; step += 64) {
+            const cplx Q = Qs[step];
+            const double aQ2 = cnorm2(Q);
+            const double den = 1.0 + (double)P.kappa * aQ2;
+            if (!(den > 0.0)) fa_atomic_or_i32(P.status, 16);
+            prod *= 1.0 / sqrt(den);
+            cplx qv;
+            if (P.modal) qv = Q * (1.0 / P.eps_t);
+            else {
+                const double aQ = sqrt(aQ2);
+                const double f = (aQ > 0.0) ? atan(aQ) / (aQ * P.eps_t) : 1.0 / P.eps_t;   // atan|Q| e^{i arg Q} / eps
+                qv = Q * f;
+            }
+            P.q[d - 1 - step] = qv;
         }
-        P.q[d - 1 - step] = qv;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) prod *= fa_shfl(prod, lane ^ off);
+        if (lane == 0) Stot[0] = prod;
+        FA_SYNC();
+        return;
     }
-    FA_SYNC();
-    if (wave == 0 || P.Ti == nullptr) return;
-    // inverse, column j = wave - 1: entries (0, 2) or (1, 3); starts as the identity (constant terms)
+    // inverse, column j = wave - 1: entries (0, 2) or (1, 3); starts as the identity (constant terms); every step
+    // matrix without its factor scl, as soon as wave 0 has published its Q
     const int j = wave - 1;
     cplx a1[R], a2[R], a10 = zero, a20 = zero;
 #pragma unroll
@@ -2921,33 +2932,43 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
         a1[s] = (K == d && j == 0) ? cmake(1.0, 0.0) : zero;
         a2[s] = (K == d && j == 1) ? cmake(1.0, 0.0) : zero;
     }
-    for (int step = 0; step < d; step++) {
+    const bool want = P.Ti != nullptr;
+    int have = 0;
+    for (int step = 0; want && step < d; step++) {
+        // bounded wait: wave 0 never waits for anybody, so `ready` reaches d; the bound only guards the exit
+        for (int spin = 0; have <= step && spin < (1 << 20); spin++) {
+            have = fa_lds_observe(ready);
+            if (have <= step) fa_nap();
+        }
+        if (have <= step) { if (lane == 0) fa_atomic_or_i32(P.status, 32); break; }
         const cplx Q = Qs[step];
-        const double scl = Ss[step];
         const cplx kQc = cconj(Q) * (double)P.kappa;
         // row 1 takes the right neighbour (multiplication by z), row 2 element-wise
         cplx r1 = fa_shfl_down_c(a1[0]), r2 = fa_shfl_down_c(a2[0]);
         if (lane == 63) { r1 = zero; r2 = zero; }
-        const cplx n10 = fa_readlane_c((a1[0] - Q * a2[0]) * scl, 0);   // new element 0 from element 1 (lane 0, slot 0)
-        const cplx n20 = (kQc * a10 + a20) * scl;
+        const cplx n10 = fa_readlane_c(a1[0] - Q * a2[0], 0);   // new element 0 from element 1 (lane 0, slot 0)
+        const cplx n20 = kQc * a10 + a20;
         cplx m1[R], m2[R];
 #pragma unroll
         for (int s = 0; s < R; s++) {
             const cplx x1 = (s == R - 1) ? r1 : a1[s + 1], x2 = (s == R - 1) ? r2 : a2[s + 1];
-            m1[s] = (x1 - Q * x2) * scl;
-            m2[s] = (kQc * a1[s] + a2[s]) * scl;
+            m1[s] = x1 - Q * x2;
+            m2[s] = kQc * a1[s] + a2[s];
         }
 #pragma unroll
         for (int s = 0; s < R; s++) { a1[s] = m1[s]; a2[s] = m2[s]; }
         a10 = n10;
         a20 = n20;
     }
+    FA_SYNC();
+    if (!want) return;
+    const double S = Stot[0];
     cplx *o1 = P.Ti + (long long)j * P.Tis, *o2 = P.Ti + (long long)(2 + j) * P.Tis;
-    if (lane == 0) { o1[0] = a10; o2[0] = a20; }
+    if (lane == 0) { o1[0] = a10 * S; o2[0] = a20 * S; }
 #pragma unroll
     for (int s = 0; s < R; s++) {
         const int K = lane * R + s + 1;
-        if (K <= d) { o1[K] = a1[s]; o2[K] = a2[s]; }
+        if (K <= d) { o1[K] = a1[s] * S; o2[K] = a2[s] * S; }
     }
 }
 

@@ -154,7 +154,7 @@ public:
             be.d2h(q, dq, deg * sizeof(cplx));
             be.d2h(hst, d_status, sizeof(hst));
             r = be.sync();
-            if (r == NFT_SUCCESS && (hst[0] & 16)) r = NFT_EC_OTHER;      // :173-176
+            if (r == NFT_SUCCESS && (hst[0] & 48)) r = NFT_EC_OTHER;      // :173-176 (bit 5: a leaf gave up waiting)
         }
         be.free(dT); be.free(dq);
         return r;      // plans and work arrays stay for the next call (destroy() releases them)
