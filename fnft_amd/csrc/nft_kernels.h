@@ -2934,14 +2934,24 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
     }
     const bool want = P.Ti != nullptr;
     int have = 0;
-    for (int step = 0; want && step < d; step++) {
-        // bounded wait: wave 0 never waits for anybody, so `ready` reaches d; the bound only guards the exit
-        for (int spin = 0; have <= step && spin < (1 << 20); spin++) {
+    // wait until wave 0 has published step `upto` (bounded: wave 0 never waits for anybody, so `ready` reaches d; the
+    // bound only guards the exit)
+    auto wait_for = [&](int upto) -> bool {
+        for (int spin = 0; have <= upto && spin < (1 << 20); spin++) {
             have = fa_lds_observe(ready);
-            if (have <= step) fa_nap();
+            if (have <= upto) fa_nap();
         }
-        if (have <= step) { if (lane == 0) fa_atomic_or_i32(P.status, 32); break; }
-        const cplx Q = Qs[step];
+        return have > upto;
+    };
+    bool ok = want && wait_for(0);
+    cplx Qnext = ok ? Qs[0] : zero;
+    if (want && !ok && lane == 0) fa_atomic_or_i32(P.status, 32);
+    for (int step = 0; ok && step < d; step++) {
+        const cplx Q = Qnext;
+        if (step + 1 < d) {   // the next step's Q is fetched now, off the dependent chain of this step
+            if (!wait_for(step + 1)) { if (lane == 0) fa_atomic_or_i32(P.status, 32); break; }
+            Qnext = Qs[step + 1];
+        }
         const cplx kQc = cconj(Q) * (double)P.kappa;
         // row 1 takes the right neighbour (multiplication by z), row 2 element-wise
         cplx r1 = fa_shfl_down_c(a1[0]), r2 = fa_shfl_down_c(a2[0]);
