@@ -1839,7 +1839,7 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge(const BigL
     }
 }
 
-// Bridge with spectral doubling (N = 2d only).  The next level's column transform of length 2*N1
+// Bridge with spectral doubling.  The next level's column transform of length 2*N1
 // of a column whose upper half is zero has, exactly,
 //     even rows  Y'[2j]   = this level's Z row j                     (nothing to compute or move),
 //     odd rows   Y'[2j+1] = DFT_N1( x[n1] * w_{2N1}^{n1} )[j]  (- t for column 0, t = product tail),
@@ -1874,22 +1874,29 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_bridge2(const Big
         L.tail_out[(size_t)e * n_out + P] = tp;
         m2 = cnorm2(tp);
     }
+    // N = 2d: coefficient 2d is folded onto 0 (un-aliased here) and the tail sits at index N, the first element
+    // of the zero upper half.  N > 2d (degrees that are not powers of two: fnft_kdvv): nothing is aliased, the
+    // tail is element 2d of the lower half, and what the transform left above it is rounding noise (zeroed here;
+    // the even rows, which are this level's Z rows, keep it -- at the level of the transform's own error)
+    const bool exact2d = ((long long)N1 * N2 == (long long)d2);
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const int n1 = v + (N1 / R) * i;
+        const long long idx = (long long)n1 * N2 + n2;
         cplx val = x[i] * inv;
-        if (n1 == 0 && n2 == 0) {
-            val = val - tp;   // un-alias coefficient 2d folded onto 0
+        if (idx == 0) {
+            if (exact2d) val = val - tp;   // un-alias coefficient 2d folded onto 0
             L.body_out[(size_t)e * L.plane + (size_t)P * d2] = val;   // the next level's "lead"
         }
+        if (!exact2d && idx > d2) val = cmake(0.0, 0.0);
         m2 = fmax(m2, cnorm2(val));
         x[i] = val * G.tw1x2[n1];   // * w_{2N1}^{n1}
     }
     fa_wave_atomic_max_hi32(&L.max2_out[(size_t)P * kMax2Slots + max2_slot()], m2);   // P is uniform in the workgroup
     fft_wg<N1, R, BC, -1, DB, true>(x, lds, v, c, G.tw1, parity);
     cplx *dst = G.Y + (size_t)poly * N1 * N2;   // odd rows only: [poly][j][n2]
-    // column 0: the tail at index N contributes t * w_{2N1}^{N1 (2j+1)} = -t to every odd row
-    const bool col0 = (n2 == 0);
+    // N = 2d, column 0: the tail at index N contributes t * w_{2N1}^{N1 (2j+1)} = -t to every odd row
+    const bool col0 = exact2d && (n2 == 0);
     cplx tpc = cmake(0.0, 0.0);
     if (col0) {
         // every lane of column 0 needs t: recompute it (cheap, uniform within the few lanes)

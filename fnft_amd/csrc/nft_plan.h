@@ -548,7 +548,7 @@ public:
                 // bridge straight into the next level's column step when that level is split too
                 const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= 512
                                         && nft_product_len(2 * d) == 2 * N;
-                const bool doubling = next_split && use_doubling && N == 2 * d;
+                const bool doubling = next_split && use_doubling && (N == 2 * d || ne == 4);
                 if (ok) {
                     if (doubling) ok = dispatch_col_bridge2(be, G);
                     else if (next_split) ok = dispatch_col_bridge(be, G);
