@@ -29,7 +29,7 @@ groups["multi2"] = ["KMulti<%d, 2>" % n for n in (16, 32, 64, 128, 256, 512, 102
 groups["leafmulti"] = ["KLeafMulti<%d, %d>" % (d, s) for s in (3, 2) for d in (1, 2, 4)]
 groups["mid"] = ["KMidSym<true>", "KMidSym<false>"]
 groups["col"] = ["KColFwd<%d>" % n for n in N1_ALL] + ["KColInv<%d>" % n for n in N1_ALL]
-groups["bridge"] = ["KColBridge<%d>" % n for n in N1_BR] + ["KColBridge2<%d>" % n for n in N1_BR]
+groups["bridge"] = ["KColBridge<%d>" % n for n in N1_BR] + ["KColBridge2<%d>" % n for n in N1_BR + [1024, 2048, 4096]]
 groups["chirpa"] = ["KChirpRows"] + ["KChirpColFwd<%d, false>" % n for n in N1_CHIRP] + ["KChirpColFwd<%d, true>" % n for n in N1_CHIRP]
 groups["chirpb"] = (["KChirpColInv<%d, false, false>" % n for n in N1_CHIRP] + ["KChirpColInv<%d, true, false>" % n for n in N1_CHIRP]
                     + ["KChirpColInv<%d, false, true>" % n for n in N1_CHIRP])

@@ -510,7 +510,7 @@ template <class BE> bool dispatch_col_bridge2(BE &be, const BigLevel &G)
     const int polys = G.L.ne * (G.L.n_in / 2);
     switch (G.N1) {
 #define X(n1) case n1: be.template run<KColBridge2<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
-        FA_FOR_EACH_BRIDGE_N1(X)
+        FA_FOR_EACH_BRIDGE_N1(X) X(1024) X(2048) X(4096)   // doubling transforms N1 points, not 2*N1
 #undef X
     default: return false;
     }
