@@ -546,7 +546,7 @@ public:
                 if (!y_from_bridge && !G.y_direct) ok = dispatch_col_fwd(be, G);
                 if (ok) run_mid(be, G);
                 // bridge straight into the next level's column step when that level is split too
-                const bool can_double = use_doubling && (N == 2 * d || ne == 4);
+                const bool can_double = use_doubling;   // N = 2d and N > 2d alike (body_col_bridge2)
                 const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= (can_double ? 4096 : 512)
                                         && nft_product_len(2 * d) == 2 * N;
                 const bool doubling = next_split && can_double;
