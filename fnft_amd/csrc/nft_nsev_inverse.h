@@ -79,6 +79,8 @@ public:
                 w.T1i = (cplx *)be.alloc(4 * (d / 2 + 1) * sizeof(cplx));
                 work.push_back(w);
                 if (!w.T2i || !w.T1 || !w.T1i) return NFT_EC_NOMEM;
+                // the upper half of T2i (coefficients 0 .. d/2 - 1 of every entry) is never written: zero once
+                be.memset0(w.T2i, 4 * (d + 1) * sizeof(cplx));
             }
             work_deg = deg;
         }
@@ -132,7 +134,7 @@ public:
         for (size_t d = work_deg; d > deg; d /= 2) slot++;
         (void)depth;
         Work &w = work[slot];
-        be.memset0(w.T2i, 4 * (deg + 1) * sizeof(cplx));                     // upper half of T2i stays zero
+        // w.T2i: the child below fills coefficients h .. deg of every entry; 0 .. h-1 are zero since init()
         peel(h, T + h, Ts, w.T2i + h, deg + 1, q + h, depth + 1);             // step 1, :107-116
         prod(deg, w.T2i, deg + 1, T, Ts, w.T1, 2 * deg + 1);                  // step 2, :120-127
         peel(h, w.T1 + deg, 2 * deg + 1, w.T1i, h + 1, q, depth + 1);         // step 3, :131-140
