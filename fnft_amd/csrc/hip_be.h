@@ -39,6 +39,8 @@ kernel_entry(const typename K::Params p)
 #endif
 
 struct HipBackend {
+    // workgroups one launch of a segmented O(n^2) kernel should have (Aberth sweeps): a few rounds of the 256 CUs
+    static constexpr size_t kTargetWorkgroups = 2048;
     hipStream_t stream = nullptr;
     bool failed = false;
     // stage timers

@@ -247,7 +247,7 @@ public:
         AberthParams A;
         A.coef = d_coef;
         A.n = (long long)n;
-        // segments of the two O(n^2) kernels: about 2048 workgroups of 256 lanes per launch.  The segment arrays
+        // segments of the two O(n^2) kernels: about BE::kTargetWorkgroups (2048) workgroups of 256 lanes per launch.  The segment arrays
         // hold kSegCap values per estimate; with fewer estimates left, a sweep uses more segments.
         constexpr size_t kSegCap = 16;
         cplx *zbuf[2] = {(cplx *)be.alloc(n * sizeof(cplx)), (cplx *)be.alloc(n * sizeof(cplx))};
@@ -281,7 +281,7 @@ public:
                 A.idx_out = ibuf[icur ^ 1];
                 A.na = (long long)na;
                 const int gx = (int)((na + 255) / 256);
-                size_t S = (2048 + (size_t)gx - 1) / (size_t)gx;
+                size_t S = (BE::kTargetWorkgroups + (size_t)gx - 1) / (size_t)gx;
                 if (S > 64) S = 64;
                 if (S * na > kSegCap * n) S = kSegCap * n / na;
                 if (n < 128 || S < 1) S = 1;

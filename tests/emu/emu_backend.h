@@ -12,6 +12,7 @@
 #include "../../fnft_amd/csrc/dev_compat.h"
 
 struct EmuBackend {
+    static constexpr size_t kTargetWorkgroups = 8;   // every emulated workgroup is a set of host threads
     void *alloc(size_t b) { return std::calloc(1, b); }
     void free(void *p) { std::free(p); }
     void h2d(void *d, const void *s, size_t b) { std::memcpy(d, s, b); }
