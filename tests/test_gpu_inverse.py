@@ -181,3 +181,42 @@ def test_argument_checks_follow_the_reference(capi):
     assert f(0, None, None, None, None, 8, [0, 1], 1)[0] == 7
     assert f(8, q8.copy(), [0, 1], None, None, 8, [0, 1], 1, {"discretization": "2SPLIT4B"})[0] == 2
     assert f(8, q8.copy(), [0, 1], [1j, 1j], [1.0, 1.0], 8, [0, 1], 1)[0] == -7     # multiplicity, :756-761
+
+
+def test_smallest_sizes_round_trip(capi, INV):
+    """D = 2 and D = 4 (one leaf block far below its capacity), M = 8: forward then inverse, both inversion methods."""
+    for D in (2, 4):
+        T = [0.0, D - 1.0]
+        q0 = np.array([0.1 + 0.05j, -0.07j, 0.02, 0.06][:D], np.complex128)
+        for kappa, method, M in ((1, "TFMATRIX_CONTAINS_REFL_COEFF", 8), (-1, "TFMATRIX_CONTAINS_AB_FROM_ITER", D)):
+            rc, XI = capi.nsev_inverse_XI(D, T, M, "2SPLIT2_MODAL")
+            assert rc == 0
+            rc, cs = capi.fnft_nsev(q0, T, M, XI, kappa=kappa, discretization="2SPLIT2_MODAL",
+                                    contspec_type="REFLECTION_COEFFICIENT")
+            assert rc == 0
+            opts = {"discretization": "2SPLIT2_MODAL", "contspec_inversion_method": method}
+            c1, c2 = cs[:M].copy(), cs[:M].copy()
+            rc, q = capi.fnft_nsev_inverse(M, c1, XI, None, None, D, T, kappa, opts)
+            assert rc == 0, capi.last_error()
+            rco, qo = INV.fnft_nsev_inverse(M, c2, XI, None, None, D, T, kappa, opts)
+            assert rco == 0
+            assert S.rel_err(q, qo) < 1e-12
+            if method.endswith("ITER"):
+                assert S.rel_err(q, q0) < 1e-13      # M = D: the iteration reproduces the samples
+
+
+def test_inner_checks_return_subroutine_codes(capi):
+    """The checks of the reference's static helpers come back through CHECK_RETCODE as -(code)."""
+    D = 8
+    T = [0.0, 7.0]
+    cs = np.full(16, 0.01 + 0.0j)
+    XI = capi.nsev_inverse_XI(D, T, 16)[1]
+    f = capi.fnft_nsev_inverse
+    # iteration method needs M = D (src/fnft_nsev_inverse.c:393-396) and kappa = -1 (:399-400)
+    assert f(16, cs.copy(), XI, None, None, D, T, -1, {"contspec_inversion_method": "TFMATRIX_CONTAINS_AB_FROM_ITER"})[0] == -2
+    assert f(8, cs[:8].copy(), XI, None, None, D, T, 1, {"contspec_inversion_method": "TFMATRIX_CONTAINS_AB_FROM_ITER"})[0] == -2
+    # B(tau) needs M = D and a symmetric time window (:643-647)
+    assert f(16, cs.copy(), None, None, None, D, T, 1, {"contspec_type": "B_OF_TAU"})[0] == -2
+    assert f(8, cs[:8].copy(), None, None, None, D, T, 1, {"contspec_type": "B_OF_TAU"})[0] == -2
+    # a seed potential together with a continuous spectrum is not a combination (:890-891)
+    assert f(8, cs[:8].copy(), XI, [1j], [1.0], D, T, 1, {"contspec_inversion_method": "USE_SEED_POTENTIAL_INSTEAD"})[0] == -2
