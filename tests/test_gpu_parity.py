@@ -664,6 +664,38 @@ def test_concurrent_host_threads(capi, oracle):
                 assert np.min(np.abs(bs - v)) < 1e-9
 
 
+def test_two_plans_two_streams_in_flight(capi):
+    """Two device plans on two streams, transforms of different signals interleaved without synchronisation in between
+    (what bench.py reports as two_in_flight): every result equals the one the same plan gives when it runs alone."""
+    import torch
+    D = M = 1 << 16
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    sig = [torch.from_numpy(S.sech_focusing(D, amp=2.0 + 0.3 * i)).cuda() for i in range(4)]
+    plans = [capi.Plan(D, M, batch=1, discretization="2SPLIT4B") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    alone = []
+    for i in range(4):                                   # reference: one at a time
+        out = torch.zeros(3 * M, dtype=torch.complex128, device="cuda")
+        st = streams[i % 2].cuda_stream
+        assert plans[i % 2].contspec_device(sig[i].data_ptr(), out.data_ptr(), T, XI, stream=st) == 0
+        assert plans[i % 2].finish(st) == 0
+        torch.cuda.synchronize()
+        alone.append(out.cpu().numpy())
+    outs = [torch.zeros(3 * M, dtype=torch.complex128, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i in range(4):                               # both streams busy at once, no host synchronisation
+            st = streams[i % 2].cuda_stream
+            assert plans[i % 2].contspec_device(sig[i].data_ptr(), outs[i].data_ptr(), T, XI, stream=st) == 0
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert plans[i].finish(streams[i].cuda_stream) == 0
+    for i in range(4):
+        assert np.array_equal(outs[i].cpu().numpy(), alone[i])   # same kernels, same order per plan: bit for bit
+    for p in plans:
+        p.close()
+
+
 def test_discrete_spectrum_options(capi, oracle, fixtures):
     """discspec_type (norming constants / residues / both, fnft_nsev.c:946-964), filtering (NONE keeps the
     spurious roots, BASIC the upper half plane, FULL the bounding box, :615-650) and a bound_states buffer
