@@ -97,6 +97,13 @@ FA_DEV double fa_shfl_down1(double v)
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// the same with zero for the last lane (bound_ctrl: lanes without a source read 0)
+FA_DEV double fa_shfl_down1_z(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 // hardware reciprocals (v_rcp_f64 / v_rcp_f32): starting values, refine where accuracy matters
 FA_DEV double fa_rcp_approx(double x) { return __builtin_amdgcn_rcp(x); }
 FA_DEV float fa_rcp_approx_f32(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -174,6 +181,7 @@ FA_DEV void fa_nap() {}
 FA_DEV double fa_readlane(double v, int) { return v; }
 FA_DEV double fa_shfl_up1(double v) { return v; }
 FA_DEV double fa_shfl_down1(double v) { return v; }
+FA_DEV double fa_shfl_down1_z(double v) { return v; }
 FA_DEV float fa_rcp_approx_f32(float x) { return 1.0f / x; }
 FA_DEV void fa_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
 FA_DEV double fa_uniform(double x) { return x; }

@@ -2854,6 +2854,7 @@ FA_DEV cplx fa_shfl_c(cplx v, int src) { return cmake(fa_shfl(v.x, src), fa_shfl
 FA_DEV cplx fa_readlane_c(cplx v, int src) { return cmake(fa_readlane(v.x, src), fa_readlane(v.y, src)); }
 FA_DEV cplx fa_shfl_up_c(cplx v) { return cmake(fa_shfl_up1(v.x), fa_shfl_up1(v.y)); }
 FA_DEV cplx fa_shfl_down_c(cplx v) { return cmake(fa_shfl_down1(v.x), fa_shfl_down1(v.y)); }
+FA_DEV cplx fa_shfl_down_cz(cplx v) { return cmake(fa_shfl_down1_z(v.x), fa_shfl_down1_z(v.y)); }
 FA_DEV void body_peel_leaf(const PeelLeafParams &P)
 {
     constexpr int R = 4;
@@ -2877,11 +2878,15 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
             t2[s] = (K <= d) ? P.T[2 * P.Ts + K] : zero;
         }
         const int lastLane = (d - 1) / R, lastSlot = (d - 1) % R;
-        for (int step = 0; step < d; step++) {
-            cplx c11 = zero, c21 = zero;                    // constant terms T11[d], T21[d]
+        // one step; SLOT3: d is a multiple of 4, the constant terms sit in slot 3; FIRST: element 0 (t10, t20) is the
+        // left neighbour of lane 0 (only step 0 ever reads it)
+        auto step_fn = [&](int step, bool slot3, bool first) {
+            cplx c11 = t1[R - 1], c21 = t2[R - 1];          // constant terms T11[d], T21[d]
+            if (!slot3) {
 #pragma unroll
-            for (int s = 0; s < R; s++)
-                if (s == lastSlot) { c11 = t1[s]; c21 = t2[s]; }
+                for (int s = 0; s < R; s++)
+                    if (s == lastSlot) { c11 = t1[s]; c21 = t2[s]; }
+            }
             c11 = fa_readlane_c(c11, lastLane);
             c21 = fa_readlane_c(c21, lastLane);
             // Q = -kappa conj(c21 / c11) = -kappa c11 conj(c21) / |c11|^2 (reciprocal by v_rcp_f64 + two Newton steps:
@@ -2895,7 +2900,7 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
             // row 1 element-wise, row 2 takes the left neighbour (division by z); without the factor scl: Q only
             // sees the ratio T21/T11, and the scale factors are multiplied onto the inverse at the end
             cplx l1 = fa_shfl_up_c(t1[R - 1]), l2 = fa_shfl_up_c(t2[R - 1]);
-            if (lane == 0) { l1 = t10; l2 = t20; }          // element 0 is only ever read in the first step
+            if (first && lane == 0) { l1 = t10; l2 = t20; }
             cplx n1[R], n2[R];
 #pragma unroll
             for (int s = 0; s < R; s++) {
@@ -2905,6 +2910,13 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
             }
 #pragma unroll
             for (int s = 0; s < R; s++) { t1[s] = n1[s]; t2[s] = n2[s]; }
+        };
+        if (lastSlot == R - 1) {
+            step_fn(0, true, true);
+            for (int step = 1; step < d; step++) step_fn(step, true, false);
+        } else {
+            step_fn(0, false, true);
+            for (int step = 1; step < d; step++) step_fn(step, false, false);
         }
         // samples and the product of the scale factors, all steps at once (off the dependent chain), :158-196
         double prod = 1.0;
@@ -2961,9 +2973,10 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
         }
         const cplx kQc = cconj(Q) * (double)P.kappa;
         // row 1 takes the right neighbour (multiplication by z), row 2 element-wise
-        cplx r1 = fa_shfl_down_c(a1[0]), r2 = fa_shfl_down_c(a2[0]);
-        if (lane == 63) { r1 = zero; r2 = zero; }
-        const cplx n10 = fa_readlane_c(a1[0] - Q * a2[0], 0);   // new element 0 from element 1 (lane 0, slot 0)
+        const cplx r1 = fa_shfl_down_cz(a1[0]), r2 = fa_shfl_down_cz(a2[0]);   // zero behind the last lane
+        // element 0 is kept by lane 0 alone (the other lanes' copies are never read): new element 0 from element 1,
+        // which is lane 0's slot 0
+        const cplx n10 = a1[0] - Q * a2[0];
         const cplx n20 = kQc * a10 + a20;
         cplx m1[R], m2[R];
 #pragma unroll
