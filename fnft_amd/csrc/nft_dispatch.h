@@ -93,6 +93,14 @@ struct KPeelImport {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_peel_import(p); }
 };
+template <int N> struct KPeelProduct {
+    using Params = PeelProdParams;
+    static constexpr int R = 8;
+    static constexpr int THREADS = 4 * N / R;
+    static constexpr int MIN_WAVES = (THREADS >= 1024) ? 4 : ((THREADS >= 512) ? 2 : 1);
+    static constexpr size_t lds_bytes() { return (size_t)4 * N * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_peel_product<N, R>(p); }
+};
 struct KPeelLeaf {
     using Params = PeelLeafParams;
     static constexpr int THREADS = 192;

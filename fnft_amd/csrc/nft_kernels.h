@@ -2830,6 +2830,75 @@ FA_DEV void body_peel_import(const PeelIoParams &P)
     else P.tail[e * 2 + m] = v;
     if (i < 2) { P.scale[i] = 1.0; P.wexp[i] = 0; }
 }
+// One 2x2 polynomial product of the layer peeling in ONE launch, for the degrees where a product is a single
+// workgroup's work anyway (deg = N/2 = 256, 512, 1024): the four entries of a factor are transformed CONCURRENTLY
+// (four groups of N/R lanes, fft_wg with B = 4) instead of one after the other, factors are read from and the result
+// is written to the caller's strided arrays (no import / export launches), cyclic length N = 2 deg with the aliased
+// top coefficient formed from the constant terms (as the tree does).  C = A * B, entries [11|12|21|22].
+struct PeelProdParams {
+    const cplx *A, *B;        // four entries of deg+1 coefficients, highest power first
+    long long As, Bs;
+    cplx *C;                  // four entries of 2 deg + 1 coefficients
+    long long Cs;
+    const cplx *tw;           // exp(-2 pi i j / N), j < N
+};
+template <int N, int R> FA_DEV void body_peel_product(const PeelProdParams &P)
+{
+    constexpr int DEG = N / 2;
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;     // N*4: transform buffer, then the spectra of one factor [bin][entry]
+    const int tid = FA_TID;
+    const int g = tid % 4, v = tid / 4; // entry of this lane's group, lane inside the group
+    const int r = g >> 1, cc = g & 1;   // row and column of the result entry this group forms
+    cplx a[R], b[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n = v + (N / R) * i;
+        a[i] = (n <= DEG) ? P.A[(long long)g * P.As + n] : cmake(0.0, 0.0);   // deg + 1 coefficients, zero-padded to N
+        b[i] = (n <= DEG) ? P.B[(long long)g * P.Bs + n] : cmake(0.0, 0.0);
+    }
+    // constant terms of the row of A and the column of B this group needs: the aliased coefficient
+    const cplx tp = P.A[(long long)(2 * r) * P.As + DEG] * P.B[(long long)cc * P.Bs + DEG]
+                  + P.A[(long long)(2 * r + 1) * P.As + DEG] * P.B[(long long)(2 + cc) * P.Bs + DEG];
+    int parity = 0;
+    fft_wg<N, R, 4, -1, false, true>(a, lds, v, g, P.tw, parity);
+    fft_wg<N, R, 4, -1, false, true>(b, lds, v, g, P.tw, parity);
+    // spectra of A through LDS: every group picks up its row
+    FA_SYNC_LDS();
+#pragma unroll
+    for (int i = 0; i < R; i++) lds[(size_t)(v + (N / R) * i) * 4 + g] = a[i];
+    FA_SYNC_LDS();
+    cplx p[R], q[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        p[i] = lds[(size_t)(v + (N / R) * i) * 4 + 2 * r];
+        q[i] = lds[(size_t)(v + (N / R) * i) * 4 + 2 * r + 1];
+    }
+    FA_SYNC_LDS();
+#pragma unroll
+    for (int i = 0; i < R; i++) lds[(size_t)(v + (N / R) * i) * 4 + g] = b[i];
+    FA_SYNC_LDS();
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx b1 = lds[(size_t)(v + (N / R) * i) * 4 + cc], b2 = lds[(size_t)(v + (N / R) * i) * 4 + 2 + cc];
+        a[i] = p[i] * b1 + q[i] * b2;
+    }
+    FA_SYNC_LDS();
+    fft_wg<N, R, 4, +1, false, true>(a, lds, v, g, P.tw, parity);
+    const double inv = 1.0 / (double)N;
+    cplx *dst = P.C + (long long)g * P.Cs;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int n = v + (N / R) * i;
+        cplx val = a[i] * inv;
+        if (n == 0) {
+            val = val - tp;          // coefficient 2 deg folded onto coefficient 0
+            dst[N] = tp;
+        }
+        dst[n] = val;
+    }
+}
+
 // One block of d <= 256 samples peeled off by one workgroup of three waves, coefficient arrays in registers (4
 // consecutive indices per lane), one sample per step: with Q = -kappa conj(T21(0)/T11(0)) (:158-176) the last step
 // matrix is divided out of the first column,

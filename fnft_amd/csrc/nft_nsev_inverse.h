@@ -36,6 +36,7 @@ inline size_t nft_next_fast_size(size_t n)
 template <class BE> class NftLayerPeelingDev {
 public:
     static constexpr size_t kLeaf = 256;
+    static constexpr size_t kOneLaunchMaxDeg = 1024;   // products up to this degree: KPeelProduct
     BE &be;
     double eps_t;
     int kappa, modal;
@@ -101,6 +102,18 @@ public:
     void prod(size_t deg, const cplx *A, size_t As, const cplx *B, size_t Bs, cplx *C, size_t Cs)
     {
         if (rc != NFT_SUCCESS) return;
+        if (deg == 256 || deg == 512 || deg == kOneLaunchMaxDeg) {   // one launch, entries transformed concurrently
+            NftPlan<BE> *tp = plan_for(kLeaf * 2);                  // any resident plan: its twiddle tables
+            if (!tp) return;
+            PeelProdParams Q;
+            std::memset(&Q, 0, sizeof(Q));
+            Q.A = A; Q.B = B; Q.As = (long long)As; Q.Bs = (long long)Bs; Q.C = C; Q.Cs = (long long)Cs;
+            Q.tw = tp->tw_table(2 * deg);
+            if (deg == 256) be.template run<KPeelProduct<512>>(1, 1, Q);
+            else if (deg == 512) be.template run<KPeelProduct<1024>>(1, 1, Q);
+            else be.template run<KPeelProduct<2048>>(1, 1, Q);
+            return;
+        }
         NftPlan<BE> *pl = plan_for(deg);
         if (!pl) return;
         PeelIoParams P;
