@@ -115,10 +115,7 @@ def bench_cfg4(args, rank, world, local_rank):
     import torch.distributed as dist
     from fnft_amd import capi
     import signals as S
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.rehearse_gloo else "nccl",
-                                **({} if args.rehearse_gloo else {"device_id": torch.device("cuda", local_rank)}))
+    # the process group (world > 1) was initialised by main()
     D = M = 1 << args.log2D
     T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
     q = S.sech_focusing(D, amp=3.2 - 0.01 * rank)
