@@ -99,6 +99,7 @@ EXPORTED = [
     "fnft__poly_fmult_two_polys", "fnft__poly_fmult_two_polys2x2", "fnft__nse_finvscatter",
     "fnft_amd_plan_last_warnings", "fnft_amd_discspec_stage_ms",
     "fnft_nsev_inverse", "fnft_nsev_inverse_default_opts", "fnft_nsev_inverse_XI", "fnft__poly_specfact",
+    "fnft__nse_scatter_matrix",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -212,6 +213,8 @@ def load(path=None):
     L.fnft_nsev_inverse_XI.argtypes = [sz, vp, sz, vp, C.c_int]
     L.fnft_nsev_inverse.restype = i32
     L.fnft_nsev_inverse.argtypes = [sz, vp, vp, sz, vp, vp, sz, vp, vp, i32, vp]
+    L.fnft__nse_scatter_matrix.restype = i32
+    L.fnft__nse_scatter_matrix.argtypes = [sz, vp, vp, dbl, i32, sz, vp, vp, C.c_int, sz]
     L.fnft__poly_specfact.restype = i32
     L.fnft__poly_specfact.argtypes = [sz, vp, vp, sz, i32]
     L.fnft__nse_finvscatter.restype = i32
@@ -431,6 +434,20 @@ def fnft_nsev_inverse(M, contspec, XI, bound_states, normconsts_or_residues, D, 
                              None if bs is None else _ptr(bs), None if nc is None else _ptr(nc), int(D), _ptr(q),
                              None if Tn is None else _ptr(Tn), int(kappa), C.byref(o))
     return int(rc), q[:int(D)]
+
+
+def nse_scatter_matrix(q, eps_t, kappa, lam, derivative=True, r=None, discretization="BO"):
+    """fnft__nse_scatter_matrix: (rc, result [K, 8 or 4]) = [S11 S12 S21 S22 (S11' S12' S21' S22')] per lambda."""
+    L = load()
+    q = _c128(q)
+    lam = _c128(lam)
+    rr = None if r is None else _c128(r)
+    w = 8 if derivative else 4
+    out = np.zeros(max(lam.size, 1) * w, np.complex128)
+    d = NSE_DISC[discretization] if isinstance(discretization, str) else int(discretization)
+    rc = L.fnft__nse_scatter_matrix(q.size, _ptr(q), None if rr is None else _ptr(rr), float(eps_t), int(kappa),
+                                    lam.size, _ptr(lam), _ptr(out), d, 1 if derivative else 0)
+    return int(rc), out[: lam.size * w].reshape(lam.size, w)
 
 
 def poly_specfact(poly, oversampling_factor, kappa):

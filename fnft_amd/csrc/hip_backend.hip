@@ -741,6 +741,53 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
     return rc;
 }
 
+// include/private/fnft__nse_scatter.h:119-123 (src/private/fnft__nse_scatter_matrix.c:33-86 ->
+// fnft__akns_scatter_matrix.c, BO scheme): S(lambda) = U_{D-1} ... U_0 and dS/dlambda for K values of lambda -- the slow
+// scatterer the periodic problem and Newton refinements call.  Chunk-parallel like the bound-state scatterer.
+FNFT_INT fnft__nse_scatter_matrix(const FNFT_UINT D, FNFT_COMPLEX const *const q, FNFT_COMPLEX *r, const FNFT_REAL eps_t,
+                                  const FNFT_INT kappa, const FNFT_UINT K, FNFT_COMPLEX const *const lambda,
+                                  FNFT_COMPLEX *const result, fnft_nse_discretization_t discretization,
+                                  const FNFT_UINT derivative_flag)
+{
+    // argument checks in the reference's order, :46-59
+    if (D == 0 || !q || !(eps_t > 0) || (kappa != 1 && kappa != -1) || K == 0 || !lambda || !result)
+        return FNFT_EC_INVALID_ARGUMENT;
+    if (discretization != fnft_nse_discretization_BO) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    HipBackend be;
+    BsParams B;
+    std::memset(&B, 0, sizeof(B));
+    size_t L = (D + 16383) / 16384;
+    if (L < 16) L = 16;
+    const size_t nchunk = (D + L - 1) / L;
+    const size_t w = derivative_flag ? 8 : 4;
+    cplx *dq = (cplx *)be.alloc(D * sizeof(cplx)), *dr = r ? (cplx *)be.alloc(D * sizeof(cplx)) : nullptr;
+    cplx *dl = (cplx *)be.alloc(K * sizeof(cplx)), *cm = (cplx *)be.alloc(K * nchunk * 8 * sizeof(cplx));
+    cplx *ds = (cplx *)be.alloc(K * w * sizeof(cplx));
+    int rc = (dq && dl && cm && ds && (!r || dr)) ? FNFT_SUCCESS : FNFT_EC_NOMEM;
+    if (rc == FNFT_SUCCESS) {
+        be.h2d(dq, q, D * sizeof(cplx));
+        if (r) be.h2d(dr, r, D * sizeof(cplx));
+        be.h2d(dl, lambda, K * sizeof(cplx));
+        B.q = dq; B.r = dr; B.kappa = (int)kappa; B.D = (long long)D; B.ups = 1; B.lscale = 1.0; B.eps = eps_t;
+        B.K = (int)K; B.lam = dl; B.L = (int)L; B.nchunk = (int)nchunk; B.cm = cm; B.smat = ds;
+        B.with_deriv = derivative_flag ? 1 : 0;
+        for (size_t k0 = 0; k0 < K; k0 += 32768) {   // grid.y limit
+            const size_t kn = std::min<size_t>(32768, K - k0);
+            BsParams Bk = B;
+            Bk.K = (int)kn; Bk.lam = dl + k0; Bk.cm = cm + k0 * nchunk * 8; Bk.smat = ds + k0 * w;
+            be.run<KBsChunk<false>>((int)((nchunk + 63) / 64), (int)kn, Bk);
+            be.run<KBsMatrix>((int)kn, 1, Bk);
+        }
+        be.d2h(result, ds, K * w * sizeof(cplx));
+        rc = be.sync();
+    }
+    be.free(dq); be.free(dr); be.free(dl); be.free(cm); be.free(ds);
+    if (be.failed) return FNFT_EC_OTHER;
+    return rc;
+}
+
 FNFT_UINT fnft__akns_fscatter_numel(FNFT_UINT D, fnft__akns_discretization_t discretization)
 {
     const int deg = nft_akns_degree((int)discretization);

@@ -57,6 +57,12 @@ template <bool BACKWARD> struct KBsCombine {
     static constexpr size_t lds_bytes() { return 256 * 12 * sizeof(cplx); }
     static FA_DEV void body(const Params &p) { body_bs_combine<BACKWARD>(p); }
 };
+struct KBsMatrix {
+    using Params = BsParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 256 * 8 * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_bs_matrix(p); }
+};
 struct KBsPhi {
     using Params = BsParams;
     static constexpr int THREADS = 64;

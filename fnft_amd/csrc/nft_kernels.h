@@ -2370,6 +2370,10 @@ struct BsParams {
     cplx *bndp;          // K*(nchunk+1)*2: psi at the same points
     cplx *PHI;           // K*(D/ups+1)*2: phi at every grid point
     cplx *PSI;           // K*(D/ups+1)*2: psi at every grid point (body_bs_psi only)
+    const cplx *r;       // NULL: r = -kappa conj(q) (forward chunk kernel; the others are focusing-only)
+    int kappa;           // -1: defocusing; anything else: focusing
+    cplx *smat;          // body_bs_matrix: K * (4 or 8) values [S11 S12 S21 S22 (S11' S12' S21' S22')]
+    int with_deriv;
     cplx *best;          // K*nchunk*2: {metric, 0}, b of the best point of the chunk
     cplx *a, *aprime, *b;
 };
@@ -2385,9 +2389,13 @@ FA_DEV void c_cosh_sinh(cplx w, cplx &ch, cplx &sh)
 
 struct BsStep { cplx u00, u01, u10, u11; };
 // step matrix for step size e (e < 0: inverse step); V (derivative) only when WITH_D
+template <bool WITH_D> FA_DEV void bs_step_r(cplx q, cplx r, cplx l, double e, BsStep &U, BsStep &V);
 template <bool WITH_D> FA_DEV void bs_step(cplx q, cplx l, double e, BsStep &U, BsStep &V)
 {
-    const cplx r = cmake(-q.x, q.y);
+    bs_step_r<WITH_D>(q, cmake(-q.x, q.y), l, e, U, V);   // r = -conj(q): focusing
+}
+template <bool WITH_D> FA_DEV void bs_step_r(cplx q, cplx r, cplx l, double e, BsStep &U, BsStep &V)
+{
     const cplx ks = q * r - l * l;
     const cplx k = c_sqrt(ks);
     cplx ch, shk;
@@ -2426,7 +2434,9 @@ template <bool BACKWARD> FA_DEV void body_bs_chunk(const BsParams &P)
     BsStep U, V;
     if (!BACKWARD) {
         for (long long n = n0; n < n1; n++) {
-            bs_step<true>(P.q[n], l, P.eps, U, V);
+            const cplx qn = P.q[n];
+            const cplx rn = P.r ? P.r[n] : (P.kappa < 0 ? cmake(qn.x, -qn.y) : cmake(-qn.x, qn.y));
+            bs_step_r<true>(qn, rn, l, P.eps, U, V);
             // M' <- V M + U M',  M <- U M
             const cplx e00 = V.u00 * m00 + V.u01 * m10 + U.u00 * d00 + U.u01 * d10;
             const cplx e01 = V.u00 * m01 + V.u01 * m11 + U.u00 * d01 + U.u01 * d11;
@@ -2555,6 +2565,46 @@ template <bool BACKWARD> FA_DEV void body_bs_combine(const BsParams &P)
             const cplx t1 = m[0] * s1 + m[1] * s2, t2 = m[2] * s1 + m[3] * s2;
             s1 = t1; s2 = t2;
         }
+    }
+}
+
+// fnft__nse_scatter_matrix (src/private/fnft__akns_scatter_matrix.c, BO): the whole scattering matrix S = U_{D-1} ...
+// U_0 and its derivative with respect to lambda from the chunk maps {M, M'}; one workgroup per lambda, every lane
+// composes its run of chunks, lane 0 the 256 run maps.
+FA_DEV void body_bs_matrix(const BsParams &P)
+{
+    FA_LDS_DECL
+    cplx *gm = (cplx *)FA_LDS_PTR;             // lanes x 8
+    const int e = FA_BID, t = FA_TID, nl = FA_BDIM;
+    const cplx *cmv = P.cm + (size_t)e * P.nchunk * 8;
+    const int G = (P.nchunk + nl - 1) / nl;
+    const int k0 = (t * G < P.nchunk) ? t * G : P.nchunk;
+    const int k1 = (k0 + G < P.nchunk) ? k0 + G : P.nchunk;
+    const cplx one = cmake(1.0, 0.0), zero = cmake(0.0, 0.0);
+    cplx m0 = one, m1 = zero, m2 = zero, m3 = one, d0 = zero, d1 = zero, d2 = zero, d3 = zero;
+    auto apply = [&](const cplx *m) {   // (M, D) <- (m M, m' M + m D)
+        const cplx e0 = m[4] * m0 + m[5] * m2 + m[0] * d0 + m[1] * d2;
+        const cplx e1 = m[4] * m1 + m[5] * m3 + m[0] * d1 + m[1] * d3;
+        const cplx e2 = m[6] * m0 + m[7] * m2 + m[2] * d0 + m[3] * d2;
+        const cplx e3 = m[6] * m1 + m[7] * m3 + m[2] * d1 + m[3] * d3;
+        d0 = e0; d1 = e1; d2 = e2; d3 = e3;
+        const cplx f0 = m[0] * m0 + m[1] * m2, f1 = m[0] * m1 + m[1] * m3;
+        const cplx f2 = m[2] * m0 + m[3] * m2, f3 = m[2] * m1 + m[3] * m3;
+        m0 = f0; m1 = f1; m2 = f2; m3 = f3;
+    };
+    for (int k = k0; k < k1; k++) apply(cmv + (size_t)k * 8);
+    cplx *o = gm + (size_t)t * 8;
+    o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m3; o[4] = d0; o[5] = d1; o[6] = d2; o[7] = d3;
+    FA_SYNC();
+    if (t != 0) return;
+    m0 = one; m1 = zero; m2 = zero; m3 = one; d0 = zero; d1 = zero; d2 = zero; d3 = zero;
+    for (int g = 0; g < nl; g++) apply(gm + (size_t)g * 8);
+    const int w = P.with_deriv ? 8 : 4;
+    cplx *res = P.smat + (size_t)e * w;
+    res[0] = m0; res[1] = m1; res[2] = m2; res[3] = m3;
+    if (P.with_deriv) {
+        const double s = P.lscale;       // chain rule of the scaled spectral parameter (1 for BO)
+        res[4] = d0 * s; res[5] = d1 * s; res[6] = d2 * s; res[7] = d3 * s;
     }
 }
 

@@ -305,6 +305,16 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
                                         FNFT_COMPLEX *a_vals, FNFT_COMPLEX *aprime_vals, FNFT_COMPLEX *b,
                                         fnft_nse_discretization_t discretization, FNFT_UINT skip_b_flag);
 
+/* include/private/fnft__nse_scatter.h:119-123 (src/private/fnft__nse_scatter_matrix.c:33-86, BO scheme of
+ * fnft__akns_scatter_matrix.c): scattering matrix S(lambda) = U_{D-1} ... U_0 of the D samples q (r = -kappa conj(q)
+ * when r == NULL) with step eps_t for K values of lambda; result holds [S11 S12 S21 S22] per lambda, followed by the
+ * derivatives with respect to lambda [S11' S12' S21' S22'] when derivative_flag != 0 (4K or 8K values).  Host buffers;
+ * chunk-parallel on the GPU.  Other discretizations: FNFT_EC_NOT_YET_IMPLEMENTED. */
+FNFT_INT fnft__nse_scatter_matrix(const FNFT_UINT D, FNFT_COMPLEX const *const q, FNFT_COMPLEX *r, const FNFT_REAL eps_t,
+                                  const FNFT_INT kappa, const FNFT_UINT K, FNFT_COMPLEX const *const lambda,
+                                  FNFT_COMPLEX *const result, fnft_nse_discretization_t discretization,
+                                  const FNFT_UINT derivative_flag);
+
 /* include/private/fnft__akns_fscatter.h:57,89-90 (src/private/fnft__akns_fscatter.c:34-42,64-925) */
 FNFT_UINT fnft__akns_fscatter_numel(FNFT_UINT D, fnft__akns_discretization_t discretization);
 FNFT_INT fnft__akns_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q,

@@ -11,6 +11,7 @@ Follows the reference file by file (citations into /root/reference, FNFT 0.4.1):
   compute_eigenfunctions                                         :908-1007
   precompensate_for_cdt_phaseshifts                              :1013-1033
   poly_specfact                   src/private/fnft__poly_specfact.c:25-140
+  nse_scatter_matrix (BO)         src/private/fnft__nse_scatter_matrix.c:33-86, fnft__akns_scatter_matrix.c
 FFTs are numpy's (any length); the reference uses KissFFT at the same lengths (fft_wrapper_next_fft_length = the
 next 2-3-5-smooth length), so results agree to round-off, not bit for bit.
 Pinned by the reference's own tests of test/fnft_nsev_inverse (tests/test_inverse_oracle.py): the sech data files as
@@ -20,7 +21,7 @@ import numpy as np
 
 from .oracle import nse_finvscatter
 
-SUCCESS, EC_INVALID_ARGUMENT, EC_SANITY = 0, 2, 9   # fnft_errwarn.h:44-108 ordinals used by the checks below
+SUCCESS, EC_INVALID_ARGUMENT, EC_SANITY = 0, 2, 7   # fnft_errwarn.h:44-108 ordinals used by the checks below
 CSTYPES = ("REFLECTION_COEFFICIENT", "B_OF_XI", "B_OF_TAU")
 CSMETHODS = ("DEFAULT", "TFMATRIX_CONTAINS_REFL_COEFF", "TFMATRIX_CONTAINS_AB_FROM_ITER", "USE_SEED_POTENTIAL_INSTEAD")
 DSTYPES = ("NORMING_CONSTANTS", "RESIDUES")
@@ -351,3 +352,31 @@ def fnft_nsev_inverse(M, contspec, XI, bound_states, normconsts_or_residues, D, 
         if rc:
             return rc, None
     return SUCCESS, q
+
+
+def nse_scatter_matrix(q, eps_t, kappa, lam, derivative=True):
+    """fnft__nse_scatter_matrix, BO scheme (src/private/fnft__akns_scatter_matrix.c: T_n = [[U, 0], [U', U]], S = T_{D-1}
+    ... T_0): [K, 8] = [S11 S12 S21 S22 S11' S12' S21' S22'] per lambda (4 columns without the derivative)."""
+    q = np.asarray(q, np.complex128)
+    r = -kappa * np.conj(q)
+    out = []
+    for l in np.asarray(lam, np.complex128):
+        S = np.eye(4, dtype=np.complex128)
+        for n in range(q.size - 1, -1, -1):
+            ks = q[n] * r[n] - l * l
+            k = np.sqrt(ks + 0j)
+            ch, sh = np.cosh(k * eps_t), np.sinh(k * eps_t) / k
+            U = np.array([[ch - 1j * l * sh, q[n] * sh], [r[n] * sh, ch + 1j * l * sh]])
+            g = l * (eps_t * ch - sh) / ks
+            Ud = np.array([[1j * eps_t * l * l * ch / ks - (l * eps_t + 1j + 1j * l * l / ks) * sh, -q[n] * g],
+                           [-r[n] * g, -1j * eps_t * l * l * ch / ks - (l * eps_t - 1j - 1j * l * l / ks) * sh]])
+            Tn = np.zeros((4, 4), np.complex128)
+            Tn[:2, :2] = U
+            Tn[2:, 2:] = U
+            Tn[2:, :2] = Ud
+            S = S @ Tn
+        row = [S[0, 0], S[0, 1], S[1, 0], S[1, 1]]
+        if derivative:
+            row += [S[2, 0], S[2, 1], S[3, 0], S[3, 1]]
+        out.append(row)
+    return np.array(out)

@@ -60,6 +60,16 @@ def main():
             for m in re.finditer(r"\b(D|M|error_bound)\s*=\s*([^;]+);", main_src):
                 ent["bounds"].append([m.start(), m.group(1), m.group(2).strip()])
             drivers[f] = ent
+    # fnft__nse_scatter_matrix known answers (test/fnft__nse_scatter/fnft__nse_scatter_matrix_test_*_bo.c): the 16 values
+    # of result_exact (two lambdas x [S11 S12 S21 S22 S11' S12' S21' S22']); inputs are formulas, restated in the tests
+    sm = {}
+    for name, kappa in (("focusing", 1), ("defocusing", -1)):
+        src = open("/root/reference/test/fnft__nse_scatter/fnft__nse_scatter_matrix_test_%s_bo.c" % name).read()
+        body = re.search(r"result_exact\[16\]\s*=\s*\{(.*?)\};", src, re.S).group(1)
+        vals = re.findall(r"([-+]?\s*\d[\d.]*(?:[eE][-+]?\d+)?)\s*([-+])\s*(\d[\d.]*(?:[eE][-+]?\d+)?)\s*\*\s*I", body)
+        assert len(vals) == 16, len(vals)
+        sm[name] = {"kappa": kappa, "result_exact": [[float(a.replace(" ", "")), float(sg + b)] for a, sg, b in vals]}
+    drivers["__nse_scatter_matrix__"] = sm
     json.dump(drivers, open(os.path.join(HERE, "inverse_fixtures.json"), "w"), indent=0)
     print("wrote inverse_sech_defocusing.npz and inverse_fixtures.json (%d drivers)" % len(drivers))
 

@@ -220,3 +220,35 @@ def test_inner_checks_return_subroutine_codes(capi):
     assert f(8, cs[:8].copy(), None, None, None, D, T, 1, {"contspec_type": "B_OF_TAU"})[0] == -2
     # a seed potential together with a continuous spectrum is not a combination (:890-891)
     assert f(8, cs[:8].copy(), XI, [1j], [1.0], D, T, 1, {"contspec_inversion_method": "USE_SEED_POTENTIAL_INSTEAD"})[0] == -2
+
+
+@pytest.mark.parametrize("name", ("focusing", "defocusing"))
+def test_nse_scatter_matrix_known_answer(capi, name):
+    """The reference's known answers of fnft__nse_scatter_matrix (BO, D = 8) through the C ABI, at the file's 10 eps."""
+    fx = IC.FIX["__nse_scatter_matrix__"][name]
+    q = 0.4 * np.cos(np.arange(1, 9)) + 0.5j * np.sin(0.3 * np.arange(1, 9))
+    rc, res = capi.nse_scatter_matrix(q, 0.13, fx["kappa"], [2.0, 1.0 + 0.5j])
+    assert rc == 0, capi.last_error()
+    exact = np.array([complex(a, b) for a, b in fx["result_exact"]])
+    assert S.rel_err(res.ravel(), exact) < 10 * np.finfo(float).eps
+
+
+@pytest.mark.parametrize("kappa", (1, -1))
+def test_nse_scatter_matrix_vs_oracle(capi, INV, kappa):
+    """Many chunks (D = 5000) and many lambdas; with and without the derivative; explicit r."""
+    rng = np.random.default_rng(5 + kappa)
+    D = 5000
+    t = S.tgrid([-10.0, 10.0], D)
+    q = (0.8 / np.cosh(t)) * np.exp(0.3j * t) + 0.01 * (rng.standard_normal(D) + 1j * rng.standard_normal(D))
+    lam = np.concatenate([np.linspace(-2, 2, 7), np.array([0.3 + 0.4j, -0.2 + 0.9j, 0.1j])])
+    eps = 20.0 / (D - 1)
+    ref = INV.nse_scatter_matrix(q, eps, kappa, lam)
+    rc, res = capi.nse_scatter_matrix(q, eps, kappa, lam)
+    assert rc == 0, capi.last_error()
+    assert S.rel_err(res, ref) < 1e-11
+    rc, res4 = capi.nse_scatter_matrix(q, eps, kappa, lam, derivative=False)
+    assert rc == 0 and np.array_equal(res4, res[:, :4])
+    rc, resr = capi.nse_scatter_matrix(q, eps, kappa, lam, r=-kappa * np.conj(q))
+    assert rc == 0 and S.rel_err(resr, res) < 1e-14
+    assert capi.nse_scatter_matrix(q, eps, kappa, lam, discretization="CF4_2")[0] == 6    # not yet implemented
+    assert capi.nse_scatter_matrix(q, -1.0, kappa, lam)[0] == 2

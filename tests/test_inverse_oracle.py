@@ -121,3 +121,14 @@ def test_argument_checks_follow_the_reference():
     assert f(8, q8, [0, 1], [-1j], [1.0], 8, [0, 1], 1)[0] == INV.EC_SANITY                    # lower half plane
     assert f(0, None, None, None, None, 8, [0, 1], 1)[0] == INV.EC_SANITY                      # nothing given
     assert f(8, q8, [0, 1], None, None, 8, [0, 1], 1, {"discretization": "2SPLIT4B"})[0] == INV.EC_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("name", ("focusing", "defocusing"))
+def test_nse_scatter_matrix_known_answer(name):
+    """test/fnft__nse_scatter/fnft__nse_scatter_matrix_test_{focusing,defocusing}_bo.c: D = 8, eps_t = 0.13, two lambdas,
+    10 eps on the 16 values."""
+    fx = IC.FIX["__nse_scatter_matrix__"][name]
+    q = 0.4 * np.cos(np.arange(1, 9)) + 0.5j * np.sin(0.3 * np.arange(1, 9))
+    res = INV.nse_scatter_matrix(q, 0.13, fx["kappa"], [2.0, 1.0 + 0.5j])
+    exact = np.array([complex(a, b) for a, b in fx["result_exact"]])
+    assert S.rel_err(res.ravel(), exact) < 10 * np.finfo(float).eps
