@@ -99,7 +99,7 @@ EXPORTED = [
     "fnft__poly_fmult_two_polys", "fnft__poly_fmult_two_polys2x2", "fnft__nse_finvscatter",
     "fnft_amd_plan_last_warnings", "fnft_amd_discspec_stage_ms",
     "fnft_nsev_inverse", "fnft_nsev_inverse_default_opts", "fnft_nsev_inverse_XI", "fnft__poly_specfact",
-    "fnft__nse_scatter_matrix",
+    "fnft__nse_scatter_matrix", "fnft__poly_roots_fftgridsearch", "fnft__poly_roots_fftgridsearch_paraherm",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
 ]
@@ -213,6 +213,9 @@ def load(path=None):
     L.fnft_nsev_inverse_XI.argtypes = [sz, vp, sz, vp, C.c_int]
     L.fnft_nsev_inverse.restype = i32
     L.fnft_nsev_inverse.argtypes = [sz, vp, vp, sz, vp, vp, sz, vp, vp, i32, vp]
+    for fn in (L.fnft__poly_roots_fftgridsearch, L.fnft__poly_roots_fftgridsearch_paraherm):
+        fn.restype = i32
+        fn.argtypes = [sz, vp, vp, vp, vp]
     L.fnft__nse_scatter_matrix.restype = i32
     L.fnft__nse_scatter_matrix.argtypes = [sz, vp, vp, dbl, i32, sz, vp, vp, C.c_int, sz]
     L.fnft__poly_specfact.restype = i32
@@ -434,6 +437,18 @@ def fnft_nsev_inverse(M, contspec, XI, bound_states, normconsts_or_residues, D, 
                              None if bs is None else _ptr(bs), None if nc is None else _ptr(nc), int(D), _ptr(q),
                              None if Tn is None else _ptr(Tn), int(kappa), C.byref(o))
     return int(rc), q[:int(D)]
+
+
+def poly_roots_fftgridsearch(p, M, PHI, paraherm=False):
+    """fnft__poly_roots_fftgridsearch(_paraherm): (rc, estimates of the roots on the arc PHI of the unit circle)."""
+    L = load()
+    p = _c128(p)
+    Mc = C.c_size_t(int(M))
+    ph = np.ascontiguousarray(PHI, np.float64)
+    roots = np.zeros(max(int(M), 1), np.complex128)
+    fn = L.fnft__poly_roots_fftgridsearch_paraherm if paraherm else L.fnft__poly_roots_fftgridsearch
+    rc = fn(p.size - 1, _ptr(p), C.byref(Mc), _ptr(ph), _ptr(roots))
+    return int(rc), roots[: int(Mc.value)].copy() if rc == 0 else roots[:0]
 
 
 def nse_scatter_matrix(q, eps_t, kappa, lam, derivative=True, r=None, discretization="BO"):

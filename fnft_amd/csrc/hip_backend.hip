@@ -741,6 +741,87 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
     return rc;
 }
 
+// include/private/fnft__poly_roots_fftgridsearch.h (src/private/fnft__poly_roots_fftgridsearch.c:35-151 and :159-217):
+// roots of a polynomial on the arc PHI of the unit circle.  *M_ptr: grid points in, estimates out; roots: *M_ptr
+// entries.  The chirp z-transforms, the candidate test and the ordered compaction run on the GPU.
+static int gridsearch_common(const size_t deg, const std::complex<double> *p, size_t *M_ptr, const double *PHI,
+                             std::complex<double> *roots, bool paraherm)
+{
+    const size_t M = *M_ptr;
+    const double eps = (PHI[1] - PHI[0]) / (double)(M - 1);
+    const std::complex<double> W(std::cos(eps), std::sin(eps));
+    HipBackend be;
+    const size_t nblk = (M + 255) / 256, rings = paraherm ? 1 : 3;
+    cplx *vals = (cplx *)be.alloc(rings * M * sizeof(cplx)), *cand = (cplx *)be.alloc(M * sizeof(cplx));
+    cplx *out = (cplx *)be.alloc(M * sizeof(cplx));
+    int *keep = (int *)be.alloc(M * sizeof(int)), *bcnt = (int *)be.alloc(nblk * sizeof(int));
+    int *boff = (int *)be.alloc(nblk * sizeof(int)), *dstatus = (int *)be.alloc(4 * sizeof(int));
+    int rc = (vals && cand && out && keep && bcnt && boff && dstatus) ? FNFT_SUCCESS : FNFT_EC_NOMEM;
+    size_t nroots = 0;
+    if (rc == FNFT_SUCCESS) {
+        be.memset0(dstatus, 4 * sizeof(int));
+        for (size_t k = 0; k < rings && rc == FNFT_SUCCESS; k++) {
+            const double scl = paraherm ? 1.0 : 1.0 + ((double)k - 1.0) * eps;      // rings k = -1, 0, 1 (:66-72)
+            const std::complex<double> A = scl * std::complex<double>(std::cos(PHI[0]), -std::sin(PHI[0]));
+            rc = Plan::chirpz_host(be, deg, p, A, W, M, nullptr, vals + k * M);
+        }
+    }
+    if (rc == FNFT_SUCCESS) {
+        GridSearchParams G;
+        std::memset(&G, 0, sizeof(G));
+        G.vals = vals; G.M = (long long)M; G.phi0 = PHI[0]; G.eps = eps; G.N1 = (long long)(deg / 2);
+        G.keep = keep; G.cand = cand; G.blockcnt = bcnt; G.blockoff = boff; G.out = out; G.status = dstatus;
+        if (paraherm) be.run<KGridMarkPh>((int)nblk, 1, G);
+        else be.run<KGridMark>((int)nblk, 1, G);
+        be.run<KCompactCount>((int)nblk, 1, G);
+        std::vector<int> hc(nblk), ho(nblk);
+        int hst[4] = {0, 0, 0, 0};
+        be.d2h(hc.data(), bcnt, nblk * sizeof(int));
+        be.d2h(hst, dstatus, sizeof(hst));
+        rc = be.sync();
+        if (rc == FNFT_SUCCESS && (hst[0] & 2)) rc = FNFT_EC_DIV_BY_ZERO;
+        if (rc == FNFT_SUCCESS) {
+            for (size_t b = 0; b < nblk; b++) { ho[b] = (int)nroots; nroots += (size_t)hc[b]; }
+            be.h2d(boff, ho.data(), nblk * sizeof(int));
+            be.run<KCompactScatter>((int)nblk, 1, G);
+            if (nroots) be.d2h(roots, out, nroots * sizeof(cplx));
+            rc = be.sync();
+        }
+    }
+    be.free(vals); be.free(cand); be.free(out); be.free(keep); be.free(bcnt); be.free(boff); be.free(dstatus);
+    if (be.failed) return FNFT_EC_OTHER;
+    if (rc == FNFT_SUCCESS) *M_ptr = nroots;
+    return rc;
+}
+FNFT_INT fnft__poly_roots_fftgridsearch(const FNFT_UINT deg, FNFT_COMPLEX const *const p, FNFT_UINT *const M_ptr,
+                                        FNFT_REAL const *const PHI, FNFT_COMPLEX *const roots)
+{
+    // argument checks in the reference's order, :46-57
+    if (deg < 2 || !p || !M_ptr || *M_ptr < 2) return FNFT_EC_INVALID_ARGUMENT;
+    if (!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY) return FNFT_EC_INVALID_ARGUMENT;
+    if (!roots) return FNFT_EC_INVALID_ARGUMENT;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    size_t M = *M_ptr;
+    const int rc = gridsearch_common(deg, p, &M, PHI, roots, false);
+    if (rc == FNFT_SUCCESS) *M_ptr = M;
+    return rc;
+}
+FNFT_INT fnft__poly_roots_fftgridsearch_paraherm(const FNFT_UINT deg, FNFT_COMPLEX const *const p, FNFT_UINT *const M_ptr,
+                                                 FNFT_REAL const *const PHI, FNFT_COMPLEX *const roots)
+{
+    // :170-180: the degree must be even
+    if (deg % 2 == 1 || deg < 2 || !p || !M_ptr || *M_ptr < 2) return FNFT_EC_INVALID_ARGUMENT;
+    if (!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY) return FNFT_EC_INVALID_ARGUMENT;
+    if (!roots) return FNFT_EC_INVALID_ARGUMENT;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    size_t M = *M_ptr;
+    const int rc = gridsearch_common(deg, p, &M, PHI, roots, true);
+    if (rc == FNFT_SUCCESS) *M_ptr = M;
+    return rc;
+}
+
 // include/private/fnft__nse_scatter.h:119-123 (src/private/fnft__nse_scatter_matrix.c:33-86 ->
 // fnft__akns_scatter_matrix.c, BO scheme): S(lambda) = U_{D-1} ... U_0 and dS/dlambda for K values of lambda -- the slow
 // scatterer the periodic problem and Newton refinements call.  Chunk-parallel like the bound-state scatterer.

@@ -87,6 +87,30 @@ struct KBsPsi {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_bs_psi(p); }
 };
+struct KGridMark {
+    using Params = GridSearchParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_gridsearch_mark(p); }
+};
+struct KGridMarkPh {
+    using Params = GridSearchParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_gridsearch_mark_ph(p); }
+};
+struct KCompactCount {
+    using Params = GridSearchParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 256 * sizeof(int); }
+    static FA_DEV void body(const Params &p) { body_compact_count(p); }
+};
+struct KCompactScatter {
+    using Params = GridSearchParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 256 * sizeof(int); }
+    static FA_DEV void body(const Params &p) { body_compact_scatter(p); }
+};
 struct KInvOp {
     using Params = InvOpParams;
     static constexpr int THREADS = 256;

@@ -2730,6 +2730,131 @@ FA_DEV void body_bs_pick(const BsParams &P)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Roots of a polynomial on an arc of the unit circle by grid search (src/private/fnft__poly_roots_fftgridsearch.c):
+// the polynomial is evaluated by chirp z-transforms (three rings, or one for the para-Hermitian form); these
+// kernels mark the grid points that hold a root estimate and then compact the estimates IN GRID ORDER (block counts,
+// host prefix over the blocks, ordered scatter) -- the reference returns them in that order.
+// ---------------------------------------------------------------------------------------------
+struct GridSearchParams {
+    const cplx *vals;      // 3*M (rings k = -1, 0, 1) or M (para-Hermitian)
+    long long M;
+    double phi0, eps;
+    long long N1;          // para-Hermitian: N - 1 = deg/2 (phase factor exp(-i phi (N-1)))
+    int *keep;             // M flags
+    cplx *cand;            // M candidates
+    int *blockcnt;         // ceil(M/256) counts
+    const int *blockoff;   // exclusive prefix of blockcnt
+    cplx *out;             // compacted estimates
+    int *status;           // bit 1: division by zero (:117-120)
+};
+// :77-146: nine-point minimum test, least-squares linear fit, root of the fit
+FA_DEV void body_gridsearch_mark(const GridSearchParams &P)
+{
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (i >= P.M) return;
+    int keep = 0;
+    cplx zr = cmake(0.0, 0.0);
+    const long long M = P.M;
+    if (i >= 1 && i < M - 1) {
+        const double c0 = cnorm2(P.vals[M + i]);
+        bool is_min = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj++)
+                if (!(k == 1 && dj == 0) && c0 > cnorm2(P.vals[(long long)k * M + i + dj])) is_min = false;
+        if (is_min) {
+            double s0, c0s;
+            fa_sincos(P.phi0 + (double)i * P.eps, &s0, &c0s);
+            const cplx z0 = cmake(c0s, s0);
+            const cplx y0 = P.vals[M + i];
+            cplx c = cmake(0.0, 0.0);
+            double den = 0.0;
+            for (long long j = i - 1; j < i + 2; j++)
+                for (int k = -1; k < 2; k++) {
+                    if (j == 0 && k == 0) continue;   // as in the reference (:99-100)
+                    double sj, cj;
+                    fa_sincos(P.phi0 + (double)j * P.eps, &sj, &cj);
+                    const cplx zi = cmake(cj, sj) * (1.0 - (double)k * P.eps);
+                    const cplx yi = P.vals[(long long)(k + 1) * M + j];
+                    c = c + cconj(zi - z0) * (yi - y0);
+                    den += cnorm2(zi - z0);
+                }
+            if (den == 0.0) fa_atomic_or_i32(P.status, 2);
+            else {
+                c = c * (1.0 / den);
+                if (c.x == 0.0 && c.y == 0.0) {
+                    if (y0.x == 0.0 && y0.y == 0.0) { keep = 1; zr = z0; }
+                } else {
+                    zr = z0 - c_div(y0, c);
+                    if (!(sqrt(cnorm2(zr - z0)) > P.eps)) keep = 1;
+                }
+            }
+        }
+    }
+    P.keep[i] = keep;
+    P.cand[i] = zr;
+}
+// para-Hermitian form (:187-214): sign change of the real part between consecutive grid points
+FA_DEV void body_gridsearch_mark_ph(const GridSearchParams &P)
+{
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    if (i >= P.M) return;
+    int keep = 0;
+    cplx zr = cmake(0.0, 0.0);
+    if (i >= 1) {
+        auto val = [&](long long m) {
+            const double phi = P.phi0 + P.eps * (double)m;
+            double sn, cs;
+            fa_sincos(-phi * (double)P.N1, &sn, &cs);
+            return P.vals[m] * cmake(cs, sn);
+        };
+        const cplx r0 = val(i - 1), r1 = val(i);
+        if (r0.x * r1.x <= 0.0) {
+            const double phi1 = P.phi0 + P.eps * (double)(i - 1), phi2 = phi1 + P.eps;
+            double phi;
+            if (r0.x != r1.x || r0.y != r1.y) phi = phi1 - c_div(r0 * (phi2 - phi1), r1 - r0).x;
+            else phi = 0.5 * (phi1 + phi2);
+            double sn, cs;
+            fa_sincos(phi, &sn, &cs);
+            zr = cmake(cs, sn);
+            keep = 1;
+        }
+    }
+    P.keep[i] = keep;
+    P.cand[i] = zr;
+}
+FA_DEV void body_compact_count(const GridSearchParams &P)
+{
+    FA_LDS_DECL
+    int *cnt = (int *)FA_LDS_PTR;
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    cnt[FA_TID] = (i < P.M) ? P.keep[i] : 0;
+    FA_SYNC();
+    for (int h = FA_BDIM / 2; h >= 1; h >>= 1) {
+        if (FA_TID < h) cnt[FA_TID] += cnt[FA_TID + h];
+        FA_SYNC();
+    }
+    if (FA_TID == 0) P.blockcnt[FA_BID] = cnt[0];
+}
+FA_DEV void body_compact_scatter(const GridSearchParams &P)
+{
+    FA_LDS_DECL
+    int *rank = (int *)FA_LDS_PTR;
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    const int k = (i < P.M) ? P.keep[i] : 0;
+    rank[FA_TID] = k;
+    FA_SYNC();
+    for (int off = 1; off < FA_BDIM; off <<= 1) {    // inclusive scan
+        const int add = (FA_TID >= off) ? rank[FA_TID - off] : 0;
+        FA_SYNC();
+        rank[FA_TID] += add;
+        FA_SYNC();
+    }
+    if (k) P.out[(long long)P.blockoff[FA_BID] + rank[FA_TID] - 1] = P.cand[i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // fnft_nsev_inverse (src/fnft_nsev_inverse.c): element-wise stages between the DFTs (chirp kernels in DFT mode) of
 // the continuous part, and the Darboux steps of the discrete part.  One kernel, selected by `op`.
 // ---------------------------------------------------------------------------------------------

@@ -737,9 +737,10 @@ public:
     }
 
     // stand-alone chirp z-transform of one host polynomial (fnft__poly_chirpz.c:33-105)
+    // d_out != NULL: the M values stay on the device (d_out), `result` is not touched
     static int chirpz_host(BE &be, size_t deg, const std::complex<double> *p,
                            std::complex<double> A, std::complex<double> Wc, size_t Mo,
-                           std::complex<double> *result)
+                           std::complex<double> *result, cplx *d_out = nullptr)
     {
         NftPlan pl(be, 2, 0, 1, 0, 1);  // only the twiddle tables of the plan are used
         size_t L = nft_nextpow2(deg + 1 + Mo - 1);
@@ -765,13 +766,13 @@ public:
             C.logA[0] = lA.real(); C.logA[1] = lA.imag();
             C.logW[0] = lW.real(); C.logW[1] = lW.imag();
             C.M = (long long)Mo;
-            C.Ybuf = dY; C.Vbuf = dV; C.Hbuf = dH;
+            C.Ybuf = dY; C.Vbuf = dV; C.Hbuf = d_out ? d_out : dH;
             pl.fill_chirp_geometry(C, L);
             C.status = dstatus;
             C.cstype = -1;
             rc = pl.run_chirp(C);
             if (rc == NFT_SUCCESS) {
-                be.d2h(result, dH, Mo * sizeof(cplx));
+                if (!d_out) be.d2h(result, dH, Mo * sizeof(cplx));
                 rc = be.sync();
             }
         }

@@ -305,6 +305,17 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
                                         FNFT_COMPLEX *a_vals, FNFT_COMPLEX *aprime_vals, FNFT_COMPLEX *b,
                                         fnft_nse_discretization_t discretization, FNFT_UINT skip_b_flag);
 
+/* include/private/fnft__poly_roots_fftgridsearch.h (src/private/fnft__poly_roots_fftgridsearch.c:35-151, :159-217):
+ * estimates of the roots of p (deg+1 coefficients, highest power first) on the arc exp(i phi), PHI[0] <= phi <= PHI[1],
+ * of the unit circle from a grid of *M_ptr points -- p evaluated on three rings by chirp z-transforms, local minima of
+ * |p|, one step of a least-squares linear fit; the para-Hermitian form (even degree) from sign changes of one ring.
+ * *M_ptr returns the number of estimates, roots (*M_ptr entries on entry) holds them in grid order.  Host buffers. */
+FNFT_INT fnft__poly_roots_fftgridsearch(const FNFT_UINT deg, FNFT_COMPLEX const *const p, FNFT_UINT *const M_ptr,
+                                        FNFT_REAL const *const PHI, FNFT_COMPLEX *const roots);
+FNFT_INT fnft__poly_roots_fftgridsearch_paraherm(const FNFT_UINT deg, FNFT_COMPLEX const *const p,
+                                                 FNFT_UINT *const M_ptr, FNFT_REAL const *const PHI,
+                                                 FNFT_COMPLEX *const roots);
+
 /* include/private/fnft__nse_scatter.h:119-123 (src/private/fnft__nse_scatter_matrix.c:33-86, BO scheme of
  * fnft__akns_scatter_matrix.c): scattering matrix S(lambda) = U_{D-1} ... U_0 of the D samples q (r = -kappa conj(q)
  * when r == NULL) with step eps_t for K values of lambda; result holds [S11 S12 S21 S22] per lambda, followed by the

@@ -12,6 +12,8 @@ Follows the reference file by file (citations into /root/reference, FNFT 0.4.1):
   precompensate_for_cdt_phaseshifts                              :1013-1033
   poly_specfact                   src/private/fnft__poly_specfact.c:25-140
   nse_scatter_matrix (BO)         src/private/fnft__nse_scatter_matrix.c:33-86, fnft__akns_scatter_matrix.c
+  poly_roots_fftgridsearch(_paraherm), misc_hausdorff_dist
+                                  src/private/fnft__poly_roots_fftgridsearch.c:35-217, fnft__misc.c:53-83
 FFTs are numpy's (any length); the reference uses KissFFT at the same lengths (fft_wrapper_next_fft_length = the
 next 2-3-5-smooth length), so results agree to round-off, not bit for bit.
 Pinned by the reference's own tests of test/fnft_nsev_inverse (tests/test_inverse_oracle.py): the sech data files as
@@ -380,3 +382,78 @@ def nse_scatter_matrix(q, eps_t, kappa, lam, derivative=True):
             row += [S[2, 0], S[2, 1], S[3, 0], S[3, 1]]
         out.append(row)
     return np.array(out)
+
+
+def _chirpz(p, A, W, M):
+    """fnft__poly_chirpz.c:28-29: p(1/(A W^-m)), m < M, p highest power first."""
+    m = np.arange(M)
+    z = 1.0 / (A * W ** (-m.astype(float)))
+    return np.polyval(np.asarray(p, np.complex128), z)
+
+
+def poly_roots_fftgridsearch(p, M, PHI):
+    """src/private/fnft__poly_roots_fftgridsearch.c:35-151."""
+    p = np.asarray(p, np.complex128)
+    eps = (PHI[1] - PHI[0]) / (M - 1)
+    W = np.exp(1j * eps)
+    vals = np.concatenate([_chirpz(p, (1.0 + k * eps) * np.exp(-1j * PHI[0]), W, M) for k in (-1, 0, 1)])
+    roots = []
+    for i in range(1, M - 1):
+        tmp = abs(vals[M + i])
+        nb = [vals[i - 1], vals[i], vals[i + 1], vals[M + i - 1], vals[M + i + 1], vals[2 * M + i - 1], vals[2 * M + i],
+              vals[2 * M + i + 1]]
+        if any(tmp > abs(v) for v in nb):
+            continue
+        z0 = np.exp(1j * (PHI[0] + i * eps))
+        y0 = vals[M + i]
+        c, den = 0.0j, 0.0
+        for j in range(i - 1, i + 2):
+            for k in (-1, 0, 1):
+                if j == 0 and k == 0:
+                    continue
+                zi = (1 - k * eps) * np.exp(1j * (PHI[0] + j * eps))
+                yi = vals[(k + 1) * M + j]
+                c += np.conj(zi - z0) * (yi - y0)
+                den += abs(zi - z0) ** 2
+        c /= den
+        if c == 0:
+            if y0 != 0:
+                continue
+            zr = z0
+        else:
+            zr = z0 - y0 / c
+            if abs(zr - z0) > eps:
+                continue
+        roots.append(zr)
+    return np.array(roots, np.complex128)
+
+
+def poly_roots_fftgridsearch_paraherm(p, M, PHI):
+    """:159-217 (even degree)."""
+    p = np.asarray(p, np.complex128)
+    deg = p.size - 1
+    eps = (PHI[1] - PHI[0]) / (M - 1)
+    v = _chirpz(p, np.exp(-1j * PHI[0]), np.exp(1j * eps), M)
+    N = deg // 2 + 1
+    phi_all = PHI[0] + eps * np.arange(M)
+    v = v * np.exp(-1j * phi_all * (N - 1))
+    roots = []
+    for i in range(1, M):
+        if v[i - 1].real * v[i].real <= 0.0:
+            phi1 = PHI[0] + eps * (i - 1)
+            phi2 = phi1 + eps
+            if v[i - 1] != v[i]:
+                phi = phi1 - (v[i - 1] * (phi2 - phi1) / (v[i] - v[i - 1])).real
+            else:
+                phi = 0.5 * (phi1 + phi2)
+            roots.append(np.exp(1j * phi))
+    return np.array(roots, np.complex128)
+
+
+def hausdorff(a, b):
+    """misc_hausdorff_dist, src/private/fnft__misc.c:53-83."""
+    a, b = np.asarray(a, np.complex128), np.asarray(b, np.complex128)
+    if a.size == 0 or b.size == 0:
+        return np.inf
+    d = np.abs(a[:, None] - b[None, :])
+    return float(max(d.min(axis=1).max(), d.min(axis=0).max()))

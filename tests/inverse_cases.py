@@ -133,3 +133,17 @@ def multisoliton_cdt(dstype, D=16384):
     return dict(M=0, contspec=None, XI=None, D=D, T=T, kappa=1, q_exact=5.0 * sech(tgrid(T, D)), bound_states=bs,
                 normconsts=nc if dstype == "NORMING_CONSTANTS" else _nc_to_residues(bs, nc),
                 bound=100 * np.finfo(float).eps, opts=dict(discspec_type=dstype))
+
+
+# ---- fnft__poly_roots_fftgridsearch known answers (test/fnft__poly/fnft__poly_roots_fftgridsearch_test_*.c) --------------
+# the polynomials and their exact unit-circle roots as the files give them; (M, bounds) schedules of the files' main()
+GRID_P_EVEN = np.array([4 - 5j, 3 - 4j, 2 - 3j, 2, 2 + 3j, 3 + 4j, 4 + 5j])
+GRID_ROOTS_EVEN = np.array([3.992603696776205e-01 + 9.168375849652399e-01j, -3.932716698145485e-01 + 9.194223152182454e-01j,
+                            9.475398776668446e-01 - 3.196375763753407e-01j, -9.853253052543915e-01 + 1.706869732151292e-01j,
+                            -7.486910771535749e-01 - 6.629190531208312e-01j, 4.384974884943283e-17 - 1.000000000000000e+00j])
+GRID_P_ODD = np.array([1, -1.58378511059697 + 2.52620897565978j, 0.46009879991909 + 1.20456190643706j,
+                       3.23268341994846 + 1.59679613801836j])
+GRID_ROOTS_ODD = np.array([0.504846104599857 + 0.863209366648873j, -0.921060994002885 - 0.38941834230865j])
+GRID_EVEN = [(128, 0.0014, 4.8e-6), (256, 0.0014 / 4, 4.8e-6 / 3.6)]       # deg_even: (M, eb1, eb2)
+GRID_ODD = [(128, 0.0003), (256, 0.0003 / 4)]                               # deg_odd: (M, eb)
+GRID_PH = [(128, 6.2e-4, 3.6e-6), (256, 6.2e-4 / 4, 3.6e-6 / 4)]              # paraherm: (M, eb1, eb2)

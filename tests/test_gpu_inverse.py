@@ -252,3 +252,53 @@ def test_nse_scatter_matrix_vs_oracle(capi, INV, kappa):
     assert rc == 0 and S.rel_err(resr, res) < 1e-14
     assert capi.nse_scatter_matrix(q, eps, kappa, lam, discretization="CF4_2")[0] == 6    # not yet implemented
     assert capi.nse_scatter_matrix(q, -1.0, kappa, lam)[0] == 2
+
+
+def _gridsearch_cases(search, search_ph, hausdorff):
+    """The three files of test/fnft__poly/fnft__poly_roots_fftgridsearch_test_*.c with their own bounds."""
+    for M, eb1, eb2 in IC.GRID_EVEN:
+        r = search(IC.GRID_P_EVEN, M, [0.0, 2 * np.pi])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN) <= eb1
+        r = search(IC.GRID_P_EVEN, M, [1.0, 1.5])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN[:1]) <= eb2
+    for M, eb in IC.GRID_ODD:
+        r = search(IC.GRID_P_ODD, M, [0.0, 2 * np.pi])
+        assert hausdorff(r, IC.GRID_ROOTS_ODD) <= eb
+    for M, eb1, eb2 in IC.GRID_PH:
+        r = search_ph(IC.GRID_P_EVEN, M, [0.0, 2 * np.pi])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN) <= eb1
+        r = search_ph(IC.GRID_P_EVEN, M, [1.0, 1.5])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN[:1]) <= eb2
+
+
+def test_poly_roots_fftgridsearch_known_answers(capi, INV):
+    def search(p, M, PHI):
+        rc, r = capi.poly_roots_fftgridsearch(p, M, PHI)
+        assert rc == 0, capi.last_error()
+        return r
+
+    def search_ph(p, M, PHI):
+        rc, r = capi.poly_roots_fftgridsearch(p, M, PHI, paraherm=True)
+        assert rc == 0, capi.last_error()
+        return r
+    _gridsearch_cases(search, search_ph, INV.hausdorff)
+
+
+def test_poly_roots_fftgridsearch_vs_oracle(capi, INV):
+    """A degree-44 polynomial with 20 roots on the unit circle, grid of 32 deg points (fnft_nsep's oversampling): the
+    same estimates in the same order as the oracle, and every root on the circle among them."""
+    rng = np.random.default_rng(11)
+    on = np.exp(1j * (0.15 + 0.3 * np.arange(20)))
+    off = rng.uniform(0.4, 0.7, 12) * np.exp(1j * rng.uniform(0, 2 * np.pi, 12))
+    roots = np.concatenate([on, off, 1.0 / np.conj(off)])       # para-Hermitian up to a phase
+    p = np.poly(roots)
+    deg = p.size - 1
+    M = 32 * deg
+    ref = INV.poly_roots_fftgridsearch(p, M, [0.0, 2 * np.pi])
+    rc, got = capi.poly_roots_fftgridsearch(p, M, [0.0, 2 * np.pi])
+    assert rc == 0 and got.size == ref.size and ref.size >= 20
+    assert np.max(np.abs(got - ref)) < 1e-9
+    assert INV.hausdorff(got, on) < 1e-3
+    assert capi.poly_roots_fftgridsearch(p[:2], 64, [0.0, 1.0])[0] == 2                      # deg < 2
+    assert capi.poly_roots_fftgridsearch(p, 64, [1.0, 0.5])[0] == 2                          # PHI
+    assert capi.poly_roots_fftgridsearch(np.poly(roots[:3]), 64, [0.0, 1.0], paraherm=True)[0] == 2   # odd degree

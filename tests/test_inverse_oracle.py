@@ -132,3 +132,24 @@ def test_nse_scatter_matrix_known_answer(name):
     res = INV.nse_scatter_matrix(q, 0.13, fx["kappa"], [2.0, 1.0 + 0.5j])
     exact = np.array([complex(a, b) for a, b in fx["result_exact"]])
     assert S.rel_err(res.ravel(), exact) < 10 * np.finfo(float).eps
+
+
+def _gridsearch_cases(search, search_ph, hausdorff):
+    """The three files of test/fnft__poly/fnft__poly_roots_fftgridsearch_test_*.c with their own bounds."""
+    for M, eb1, eb2 in IC.GRID_EVEN:
+        r = search(IC.GRID_P_EVEN, M, [0.0, 2 * np.pi])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN) <= eb1
+        r = search(IC.GRID_P_EVEN, M, [1.0, 1.5])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN[:1]) <= eb2
+    for M, eb in IC.GRID_ODD:
+        r = search(IC.GRID_P_ODD, M, [0.0, 2 * np.pi])
+        assert hausdorff(r, IC.GRID_ROOTS_ODD) <= eb
+    for M, eb1, eb2 in IC.GRID_PH:
+        r = search_ph(IC.GRID_P_EVEN, M, [0.0, 2 * np.pi])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN) <= eb1
+        r = search_ph(IC.GRID_P_EVEN, M, [1.0, 1.5])
+        assert hausdorff(r, IC.GRID_ROOTS_EVEN[:1]) <= eb2
+
+
+def test_poly_roots_fftgridsearch_known_answers():
+    _gridsearch_cases(INV.poly_roots_fftgridsearch, INV.poly_roots_fftgridsearch_paraherm, INV.hausdorff)
