@@ -76,12 +76,14 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
             kind, lv = "leaf", 0
         elif base == "KMulti":
             kind, lv = "fused levels " + n, int(re.findall(r"\d+", n)[-1])
-        elif base in ("KPairSchool", "KPairFft"):
+        elif base in ("KPairSchool", "KPairFft", "KRPairSchool", "KRPair"):
             kind, lv = "single-launch levels", 1
         elif base in ("KMid", "KMidSym"):
             kind, lv = "split levels", 1
-        elif base == "KColFwd":
+        elif base in ("KColFwd", "KRColFwd"):
             kind, lv = "split levels", 0
+        elif base == "KRealCheck":
+            kind, lv = "leaf", 0
         else:   # KColBridge*, KColInv, KFinalizeScales: belong to the level that is open
             kind, lv = (groups[-1][0] if groups else "leaf"), 0
         if groups and groups[-1][0] == kind:

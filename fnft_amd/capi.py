@@ -101,7 +101,7 @@ EXPORTED = [
     "fnft_nsev_inverse", "fnft_nsev_inverse_default_opts", "fnft_nsev_inverse_XI", "fnft__poly_specfact",
     "fnft__nse_scatter_matrix", "fnft__poly_roots_fftgridsearch", "fnft__poly_roots_fftgridsearch_paraherm",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
-    "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device",
+    "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device", "fnft_amd_kdvv_plan_set_real_mode",
 ]
 
 _lib = None
@@ -163,6 +163,8 @@ def load(path=None):
     L.fnft__kdv_fscatter.argtypes = [sz, vp, dbl, vp, C.POINTER(sz), C.POINTER(i32), C.c_int]
     L.fnft_amd_kdvv_plan_create.restype = i32
     L.fnft_amd_kdvv_plan_create.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int]
+    L.fnft_amd_kdvv_plan_set_real_mode.restype = i32
+    L.fnft_amd_kdvv_plan_set_real_mode.argtypes = [vp, C.c_int]
     L.fnft_amd_kdvv_contspec_device.restype = i32
     L.fnft_amd_kdvv_contspec_device.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl), vp]
     L.fnft_amd_plan_create_sub.restype = i32
@@ -614,6 +616,10 @@ class KdvvPlan:
             self.close()
         except Exception:
             pass
+
+    def set_real_mode(self, mode):
+        """-1: ask the device whether u is real (default); 1: u is real (real-coefficient tree); 0: complex tree."""
+        return int(self.L.fnft_amd_kdvv_plan_set_real_mode(self.h, int(mode)))
 
     def set_timing(self, on=True):
         self.L.fnft_amd_plan_set_timing(self.h, 1 if on else 0)

@@ -27,6 +27,7 @@ struct fnft_amd_plan {
     int device = 0;
     int nse_disc = 0;
     int kdv_disc = -1;   // >= 0: plan made by fnft_amd_kdvv_plan_create
+    int real_mode = -1;  // KdV plans: -1 ask the device whether the potential is real (default), 0 complex path, 1 real path
     std::mutex mtx;
 };
 
@@ -339,6 +340,22 @@ FNFT_INT fnft_amd_kdvv_contspec_device(fnft_amd_plan_t *plan, const void *d_u, v
     plan->be.stream = (hipStream_t)stream;
     plan->be.failed = false;
     plan->be.mark(0);
+    // a real potential takes the real-coefficient tree (nft_real.h: half the transforms and bytes); in the default mode
+    // the device is asked first -- one small kernel and a 4-byte read-back, i.e. this call then waits for the stream once
+    bool real = plan->real_mode == 1;
+    if (plan->real_mode < 0) {
+        RealCheckParams R;
+        R.q = (const cplx *)d_u;
+        R.n = (long long)(pl.batch * pl.D);
+        R.flag = pl.status + 1;
+        plan->be.run<KRealCheck>((int)std::min<long long>(1024, (R.n + 255) / 256), 1, R);
+        int flag = 1;
+        plan->be.d2h(&flag, pl.status + 1, sizeof(int));
+        if (plan->be.sync() != NFT_SUCCESS) return FNFT_EC_OTHER;
+        if (flag) plan->be.memset0(pl.status + 1, sizeof(int));
+        real = (flag == 0);
+    }
+    pl.want_real = real;
     double Tsub[2];
     int rc = pl.run_front(d_u, T, 1, Tsub);
     if (rc == NFT_SUCCESS) rc = pl.run_tree();
@@ -348,6 +365,14 @@ FNFT_INT fnft_amd_kdvv_contspec_device(fnft_amd_plan_t *plan, const void *d_u, v
     plan->be.mark(2);
     if (plan->be.failed) return FNFT_EC_OTHER;
     return rc;
+}
+
+FNFT_INT fnft_amd_kdvv_plan_set_real_mode(fnft_amd_plan_t *plan, int mode)
+{
+    if (!plan || plan->kdv_disc < 0 || mode < -1 || mode > 1) return FNFT_EC_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(plan->mtx);
+    plan->real_mode = mode;
+    return FNFT_SUCCESS;
 }
 
 FNFT_INT fnft_amd_plan_finish(fnft_amd_plan_t *plan, void *stream)
@@ -928,10 +953,9 @@ FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, cons
     if (kd < 0 || kd > (int)fnft_kdv_discretization_2SPLIT8B) return FNFT_EC_INVALID_ARGUMENT;
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
-    std::vector<std::complex<double>> r(D, std::complex<double>(-1.0, 0.0));
     HipBackend be;
-    return api_akns_fscatter(be, D, (const std::complex<double> *)u, r.data(), eps_t, 1,
-                             (std::complex<double> *)result, deg_ptr, W_ptr, kd + 1);
+    return api_kdv_fscatter(be, D, (const std::complex<double> *)u, eps_t, (std::complex<double> *)result, deg_ptr,
+                            W_ptr, kd + 1);
 }
 
 // internal entry used by fnft_kdvv_host.c: host buffers in and out, plans cached per (D, M, scheme)
@@ -965,6 +989,12 @@ FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const 
     if (!hip_ok(hipMalloc((void **)&dcs, M * sizeof(cplx)), "hipMalloc")) {
         (void)hipFree(du);
         return FNFT_EC_NOMEM;
+    }
+    {   // the potential is in host memory: look at it here instead of asking the device
+        bool real = true;
+        const std::complex<double> *uh = (const std::complex<double> *)u;
+        for (size_t i = 0; i < D && real; i++) real = (uh[i].imag() == 0.0);
+        P->real_mode = real ? 1 : 0;
     }
     FNFT_INT rc = FNFT_SUCCESS;
     if (!hip_ok(hipMemcpy(du, u, D * sizeof(cplx), hipMemcpyHostToDevice), "hipMemcpy(H2D)")) rc = FNFT_EC_OTHER;

@@ -80,3 +80,47 @@ int api_akns_fscatter(BE &be, size_t D, const std::complex<double> *q, const std
     pl.destroy();
     return rc;
 }
+
+// fnft__kdv_fscatter, src/private/fnft__kdv_fscatter.c:45-83: r = -1 for every sample; a real potential takes the
+// real-coefficient tree (nft_real.h)
+template <class BE>
+int api_kdv_fscatter(BE &be, size_t D, const std::complex<double> *u, double eps_t, std::complex<double> *result,
+                     size_t *deg_ptr, int32_t *W_ptr, int akns_disc)
+{
+    const int deg0 = nft_akns_degree(akns_disc);
+    if (deg0 == 0) return NFT_EC_INVALID_ARGUMENT;
+    bool real = true;
+    for (size_t i = 0; i < D && real; i++) real = (u[i].imag() == 0.0);
+    NftPlan<BE> pl(be, D, 0, 1, akns_disc, deg0);
+    pl.kdv = true;
+    pl.want_real = real;
+    int rc = pl.init();
+    cplx *dq = nullptr;
+    if (rc == NFT_SUCCESS && !pl.alloc(dq, D)) rc = NFT_EC_NOMEM;
+    if (rc == NFT_SUCCESS) {
+        be.h2d(dq, u, D * sizeof(cplx));
+        rc = pl.run_coeffs(dq, pl.rneg, eps_t, 1);
+    }
+    if (rc == NFT_SUCCESS) rc = pl.run_tree();
+    if (rc == NFT_SUCCESS) {
+        pl.export_tm();
+        const size_t cnt = 4 * (pl.res_deg + 1);
+        be.d2h(result, pl.tm_out, cnt * sizeof(cplx));
+        int W = 0;
+        be.d2h(&W, pl.wexp[pl.cur], sizeof(int));
+        rc = pl.read_status();
+        if (rc == -NFT_EC_OTHER) rc = NFT_EC_OTHER;
+        if (rc == NFT_SUCCESS) {
+            *deg_ptr = pl.res_deg;
+            if (W_ptr) {
+                *W_ptr = W;
+            } else {
+                const double s = std::ldexp(1.0, W);
+                for (size_t i = 0; i < cnt; i++) result[i] *= s;
+            }
+        }
+    }
+    be.free(dq);
+    pl.destroy();
+    return rc;
+}

@@ -5,6 +5,7 @@
 // A back end BE provides: template<class K> void run(int gx, int gy, const typename K::Params&).
 #pragma once
 #include "nft_kernels.h"
+#include "nft_real.h"
 
 #ifndef FA_ROW_TREE
 #define FA_ROW_TREE 2048
@@ -572,3 +573,119 @@ template <class BE> bool dispatch_chirp_col_inv(BE &be, const ChirpParams &C)
     default: return false;
     }
 }
+
+// ---- real-coefficient path (nft_real.h) -----------------------------------------------------------
+constexpr int kRealFusedMaxM = 2048;   // largest folded transform done by one workgroup
+template <int DEG> struct KRPairSchool {
+    using Params = TreeLevel;
+    static constexpr int THREADS = 128;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_rpair_school<DEG>(p); }
+};
+template <int M> struct RPairCfg {
+    static constexpr int R = 4;
+    static constexpr int THREADS = (M / R > 256) ? M / R : 256;
+    static constexpr int B = THREADS / (M / R);
+    static constexpr bool DB = true;
+};
+template <int M> struct KRPair {
+    using Params = TreeLevel;
+    using C = RPairCfg<M>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes()
+    {
+        return ((M > C::R && C::DB) ? (size_t)2 : (size_t)1) * M * C::B * sizeof(cplx)
+               + ((M > C::R && M <= 512) ? (size_t)M * sizeof(cplx) : 0) + (size_t)C::B * 8;
+    }
+    static FA_DEV void body(const Params &p) { body_rpair<M, C::R, C::B, C::DB>(p); }
+};
+template <int N1> struct KRColFwd {
+    using Params = BigLevel;
+    using C = ColCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_rcol_fwd<N1, C::R, C::BC, C::DB>(p); }
+};
+template <int N1> struct KRColInv {
+    using Params = BigLevel;
+    using C = ColCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_rcol_inv<N1, C::R, C::BC, C::DB>(p); }
+};
+// bridge of the real path: R points of the inverse and 2R of the forward transform per lane; 8 keeps it under 128
+// registers (16: 270-280, one wave per SIMD)
+template <int N1> struct RBridgeCfg {
+    static constexpr int R = (N1 <= 8) ? N1 : 8;
+    static constexpr int THREADS = (N1 >= 512) ? 512 : 256;
+    static constexpr int BC = THREADS / (N1 / R);
+    static constexpr bool DB = false;
+    static constexpr size_t lds_bytes() { return (N1 > R) ? (size_t)2 * N1 * BC * sizeof(cplx) : 0; }
+};
+template <int N1> struct KRBridge {
+    using Params = BigLevel;
+    using C = RBridgeCfg<N1>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes() { return C::lds_bytes(); }
+    static FA_DEV void body(const Params &p) { body_rbridge<N1, C::R, C::BC, C::DB>(p); }
+};
+template <class BE> bool dispatch_rpair_school(BE &be, const TreeLevel &L)
+{
+    const int g = (L.n_in / 2 + 127) / 128;
+    switch (L.d) {
+    case 1: be.template run<KRPairSchool<1>>(g, 1, L); return true;
+    case 2: be.template run<KRPairSchool<2>>(g, 1, L); return true;
+    case 3: be.template run<KRPairSchool<3>>(g, 1, L); return true;
+    default: return false;
+    }
+}
+#define FA_FOR_EACH_RPAIR_M(X) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
+template <class BE> bool dispatch_rpair(BE &be, const TreeLevel &L, int M)
+{
+    const int pairs = L.n_in / 2;
+    switch (M) {
+#define X(m) case m: be.template run<KRPair<m>>((pairs + RPairCfg<m>::B - 1) / RPairCfg<m>::B, 1, L); return true;
+        FA_FOR_EACH_RPAIR_M(X)
+#undef X
+    default: return false;
+    }
+}
+#define FA_FOR_EACH_RCOL_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096)
+template <class BE> bool dispatch_rcol_fwd(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * G.L.n_in;
+    switch (G.N1) {
+#define X(n1) case n1: be.template run<KRColFwd<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
+        FA_FOR_EACH_RCOL_N1(X)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_rcol_inv(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * (G.L.n_in / 2);
+    switch (G.N1) {
+#define X(n1) case n1: be.template run<KRColInv<n1>>(G.N2 / ColCfg<n1>::BC, polys, G); return true;
+        FA_FOR_EACH_RCOL_N1(X)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_rbridge(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * (G.L.n_in / 2);
+    switch (G.N1) {
+#define X(n1) case n1: be.template run<KRBridge<n1>>(G.N2 / RBridgeCfg<n1>::BC, polys, G); return true;
+        FA_FOR_EACH_BRIDGE_N1(X)
+#undef X
+    default: return false;
+    }
+}
+struct KRealCheck {
+    using Params = RealCheckParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_real_check(p); }
+};

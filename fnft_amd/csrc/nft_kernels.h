@@ -56,6 +56,7 @@ struct TreeLevel {
     int kappa;                     // +1 focusing / -1 defocusing (symmetric form only)
     int dbg;                       // diagnostic builds (-DFNFT_AMD_ABLATION) only: 1 skip transforms, 2 skip loads, 4 skip stores
     const cplx *twm[3];            // multi-level kernel (body_multi_fft): tables for N0, 2*N0, 4*N0
+    const cplx *twx = nullptr;     // real-coefficient path (nft_real.h): exp(-2 pi i j/(4M)), M = transform length
 };
 
 // floor(log2(sqrt(m2))) for m2 > 0 (normal), exactly, from the exponent field
@@ -201,6 +202,8 @@ struct CoeffParams {
     int D, Dpad, batch, kappa;
     int disc;            // fnft__akns_discretization_t ordinal
     int deg;
+    int real_out = 0;    // real-coefficient path (nft_real.h): body/tail are arrays of double (real parts only);
+                         // a sample with a non-zero imaginary part sets bit 3 of the status word
 };
 
 // coefficient tables: P[e][k], k <= deg, highest power first
@@ -327,6 +330,7 @@ template <int DEG> FA_DEV void body_coeffs(const CoeffParams &P)
         const cplx q = P.q[src];
         const cplx r = P.r ? P.r[src] : (P.kappa == 1 ? cmake(-q.x, q.y) : cmake(q.x, -q.y));
         if (!sample_coeffs<DEG>(P.disc, P.eps_t, q, r, m)) fa_atomic_or_i32(P.status, 1);
+        if (P.real_out && (q.y != 0.0 || r.y != 0.0)) fa_atomic_or_i32(P.status, 8);
     } else {
         coeffs_zero(m);
         if (P.ne == 4) {
@@ -341,6 +345,13 @@ template <int DEG> FA_DEV void body_coeffs(const CoeffParams &P)
     for (int e = 0; e < 4; e++) {
         if (P.ne == 2 && (e & 1)) continue;
         const int s = (P.ne == 2) ? (e >> 1) : e;
+        if (P.real_out) {   // real-coefficient path: arrays of double
+            double *rb = (double *)P.body, *rt = (double *)P.tail;
+#pragma unroll
+            for (int k = 0; k < DEG; k++) rb[(size_t)s * P.plane + (size_t)gid * DEG + k] = m.p[e][k].x;
+            rt[(size_t)s * n + gid] = m.p[e][DEG].x;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < DEG; k++) P.body[(size_t)s * P.plane + (size_t)gid * DEG + k] = m.p[e][k];
         P.tail[(size_t)s * n + gid] = m.p[e][DEG];
@@ -383,6 +394,7 @@ FA_DEV void body_coeffs_prog(const CoeffProgParams &Q)
         const size_t src = (size_t)b * P.D + (size_t)(P.D - 1 - j);
         const cplx q = P.q[src];
         const cplx r = P.r ? P.r[src] : (P.kappa == 1 ? cmake(-q.x, q.y) : cmake(q.x, -q.y));
+        if (P.real_out && (q.y != 0.0 || r.y != 0.0)) fa_atomic_or_i32(P.status, 8);
         for (int i = 0; i < Q.nB; i++) {
             const StepExp e = zero_freq_step(P.eps_t * Q.bfrac[i], q, r);
             el[(3 * i) * 64 + lane] = e.c;
@@ -417,14 +429,19 @@ FA_DEV void body_coeffs_prog(const CoeffProgParams &Q)
                     }
                 }
                 if (k < deg) stage[lane * CH + (k - k0)] = acc;
-                else if (act) P.tail[(size_t)s * n + gid] = acc;
+                else if (act) {
+                    if (P.real_out) ((double *)P.tail)[(size_t)s * n + gid] = acc.x;
+                    else P.tail[(size_t)s * n + gid] = acc;
+                }
             }
             FA_SYNC();
             const int cw = (deg - k0 < CH) ? deg - k0 : CH;   // body coefficients of this round (the last one is the tail)
+            double *rbody = (double *)P.body + (size_t)s * P.plane + (size_t)gid0 * deg;
             for (long long i = lane; i < nact * cw; i += 64) {
                 const long long smp = i / cw;
                 const int kk = (int)(i % cw);
-                body[smp * deg + k0 + kk] = stage[smp * CH + kk];
+                if (P.real_out) rbody[smp * deg + k0 + kk] = stage[smp * CH + kk].x;
+                else body[smp * deg + k0 + kk] = stage[smp * CH + kk];
             }
             FA_SYNC();
         }
@@ -484,6 +501,7 @@ template <int DEG> FA_DEV bool leaf_sample(const CoeffParams &P, int b, long lon
         const size_t src = (size_t)b * P.D + (size_t)(P.D - 1 - j);
         const cplx q = P.q[src];
         const cplx r = P.r ? P.r[src] : (P.kappa == 1 ? cmake(-q.x, q.y) : cmake(q.x, -q.y));
+        if (P.real_out && (q.y != 0.0 || r.y != 0.0)) fa_atomic_or_i32(P.status, 8);
         return sample_coeffs<DEG>(P.disc, P.eps_t, q, r, m);
     }
     coeffs_zero(m);
@@ -561,13 +579,16 @@ template <int DEG, int SPT> FA_DEV void body_leaf(const LeafParams &LP)
         if (active) {
 #pragma unroll
             for (int k = 0; k < d; k++) stage[(size_t)tid * d + ((k + tid) % d)] = acc[e][k] * sc;
-            P.tail[(size_t)s * n_out + gid] = acc[e][d] * sc;
+            if (P.real_out) ((double *)P.tail)[(size_t)s * n_out + gid] = acc[e][d].x * sc;
+            else P.tail[(size_t)s * n_out + gid] = acc[e][d] * sc;
         }
         FA_SYNC();
         cplx *out0 = P.body + (size_t)s * P.plane + (size_t)g0 * d;
+        double *rout0 = (double *)P.body + (size_t)s * P.plane + (size_t)g0 * d;
         for (int m = tid; m < total; m += FA_BDIM) {
             const int t2 = m / d, k2 = m - t2 * d;
-            out0[m] = stage[(size_t)t2 * d + ((k2 + t2) % d)];
+            if (P.real_out) rout0[m] = stage[(size_t)t2 * d + ((k2 + t2) % d)].x;
+            else out0[m] = stage[(size_t)t2 * d + ((k2 + t2) % d)];
         }
         FA_SYNC();
     }
@@ -1318,6 +1339,11 @@ struct BigLevel {
     // first split level with N1 = 4 and N = 2d: no column kernel -- the row kernel forms the length-4
     // column transform itself, Y[k1][n2] = x[n2] + i^(-k1) x[N2 + n2] (+ (-1)^k1 tail at n2 = 0)
     int y_direct;
+    // real-coefficient path (nft_real.h): btw is the table of length 4*N and the row twiddle of row k1 is
+    // w_{4N}^{(4 k1 - 1) n2} (transform of the twisted sequence: evaluation at the roots of x^N = i);
+    // twq / twq2: exp(-2 pi i j/(4 N1)) and exp(-2 pi i j/(8 N1)) for the column kernels
+    int rtwist = 0;
+    const cplx *twq = nullptr, *twq2 = nullptr;
     int stagger;     // row kernel: start delay of the second half of the grid, units of ~1024 clocks (0: none)
     // diagnostic builds (-DFNFT_AMD_STAMPS) only: per-wave s_memtime stamps of the row kernel's phases,
     // 16 slots per wave, or NULL
@@ -1394,6 +1420,16 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLeve
 
 // row step: one workgroup per (pair, k1): forward row transforms of every stored entry of both
 // factors, products, inverse row transforms (8 + 4 general, 4 + 2 symmetric)
+// index into the row-twiddle table of a split level: w_N^{k1 x}, or -- real-coefficient path (BigLevel::rtwist, table of
+// length 4N) -- w_{4N}^{(4 k1 - 1) x}
+FA_DEV unsigned row_tw_index(const BigLevel &G, int k1, int x)
+{
+    if (!G.rtwist) return (unsigned)k1 * (unsigned)x;
+    const unsigned long long len4 = 4ull * (unsigned long long)G.N1 * (unsigned long long)G.N2;   // a power of two
+    const unsigned long long c1 = 4ull * (unsigned long long)k1 + len4 - 1ull;                     // 4 k1 - 1 (mod 4N)
+    return (unsigned)((c1 * (unsigned long long)x) & (len4 - 1ull));
+}
+
 template <int N2, int R> struct MidIO {
     const BigLevel &G;
     long long P;
@@ -1407,11 +1443,11 @@ template <int N2, int R> struct MidIO {
         k1 = FA_BID % G.N1;
 #pragma unroll
         for (int i = 1; i < R; i++) {
-            const cplx w = big_twiddle(G.btw, (unsigned)k1 * (unsigned)((N2 / R) * i));
+            const cplx w = big_twiddle(G.btw, row_tw_index(G, k1, (N2 / R) * i));
             wu[i] = cmake(fa_uniform(w.x), fa_uniform(w.y));
         }
         wu[0] = cmake(1.0, 0.0);
-        wbase = big_twiddle(G.btw, (unsigned)k1 * (unsigned)FA_TID);
+        wbase = big_twiddle(G.btw, row_tw_index(G, k1, FA_TID));
         sc[0] = (G.y_unscaled || G.y_direct) ? level_in_scale(G.L, 2 * P) : 1.0;
         sc[1] = (G.y_unscaled || G.y_direct) ? level_in_scale(G.L, 2 * P + 1) : 1.0;
         // bookkeeping of the level, done once per pair before the column kernel that follows:
@@ -1940,6 +1976,7 @@ struct ExportParams {
     int kappa;
     long long out_stride = 0;   // != 0 (batch 1): entry e goes to out[e*out_stride + k] instead of out[e*(deg+1) + k]
     const int *W = nullptr;     // != NULL: values are multiplied by 2^W[0] (un-normalised result)
+    int real_layout = 0;        // body/tail are arrays of double (real-coefficient path, nft_real.h)
 };
 // coefficient k (highest power first, k <= deg) of stored plane s of signal b.  General form:
 // identity padding z^deg0*I leaves TRAILING zeros, index k.  Symmetric form: padding with the
@@ -1952,6 +1989,13 @@ FA_DEV cplx stored_coef(const cplx *body, const cplx *tail, size_t plane, long l
     if (kk < deg_tot) return body[(size_t)s * plane + (size_t)b * deg_tot + kk];
     return tail[(size_t)s * batch + b];
 }
+// the same for the real-coefficient layout (arrays of double, general form only)
+FA_DEV cplx stored_coef_real(const cplx *body, const cplx *tail, size_t plane, long long deg_tot, int batch, int s, int b,
+                             long long k)
+{
+    if (k < deg_tot) return cmake(((const double *)body)[(size_t)s * plane + (size_t)b * deg_tot + k], 0.0);
+    return cmake(((const double *)tail)[(size_t)s * batch + b], 0.0);
+}
 FA_DEV void body_export_tm(const ExportParams &E)
 {
     const long long gid = (long long)FA_BID * FA_BDIM + FA_TID;
@@ -1963,7 +2007,9 @@ FA_DEV void body_export_tm(const ExportParams &E)
     const long long k = r % (E.deg + 1);
     const double sc = E.scale[b];
     cplx val;
-    if (E.ne == 4) {
+    if (E.real_layout) {
+        val = stored_coef_real(E.body, E.tail, E.plane, E.deg_tot, E.batch, e, b, k);
+    } else if (E.ne == 4) {
         val = stored_coef(E.body, E.tail, E.plane, E.deg_tot, E.deg, E.batch, 4, e, b, k);
     } else if (e == 0 || e == 2) {       // 11, 21 are stored
         val = stored_coef(E.body, E.tail, E.plane, E.deg_tot, E.deg, E.batch, 2, e >> 1, b, k);
@@ -2026,6 +2072,7 @@ struct ChirpParams {
     // between calls with the same grids.  v_mode 0: compute; 1: compute and store; 2: load
     cplx *VS;
     int v_mode;
+    int real_layout;     // body/tail are arrays of double (real-coefficient path, nft_real.h)
 };
 
 // exp((xr + i*xi)) with a real multiplier folded in: returns exp(t*lr) * cis(t*li)
@@ -2076,6 +2123,8 @@ template <bool DFT> FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int
     if (C.poly && C.poly_tm)   // transfer matrices in the reference layout [r11|r12|r21|r22] per signal
         return C.poly[((size_t)b * 4 + C.entry[slot]) * (size_t)(C.deg + 1) + (size_t)k];
     if (C.poly) return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)k];
+    if (C.real_layout)
+        return stored_coef_real(C.body, C.tail, C.plane, C.deg_tot, C.batch, C.entry[slot], b, k) * C.scale[b];
     return stored_coef(C.body, C.tail, C.plane, C.deg_tot, C.deg, C.batch, C.ne, C.entry[slot], b, k)
            * C.scale[b];
 }

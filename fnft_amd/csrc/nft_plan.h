@@ -106,7 +106,8 @@ inline size_t nft_product_len(size_t d)
 }
 
 constexpr int kFineLog2 = 12;           // master twiddle: NMAX = 2^24
-constexpr int kMaxTwTable = 8192;       // per-length tables up to this length (longest column transform)
+constexpr int kMaxTwTable = 16384;      // per-length tables up to this length (longest column transform; the real path's
+                                        // quarter-step tables of 4*N1 entries)
 constexpr size_t kMaxSplitTree = (size_t)kRowTree * 8192;    // largest column transform: 8192 (N up to 2^24)
 constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 4096;  // chirp length up to 2^24
 
@@ -133,6 +134,11 @@ public:
     // KdV (fnft_kdvv): r = -1 for every sample (fnft__kdv_fscatter.c:74-75), general 2x2 tree
     bool kdv = false;
     cplx *rneg = nullptr;
+    // real-coefficient path (nft_real.h): r = -1 and a real potential make every coefficient real.  want_real is the
+    // caller's request for the NEXT run_front / run_coeffs (hip_backend.hip decides per call); real_run says which layout
+    // the current level arrays hold
+    bool want_real = false;
+    bool real_run = false;
     // 4SPLIT4A/B front end (set_front): Din input samples per signal, every nskip-th step kept,
     // ups preprocessed samples per kept step; D = ups * Dsub matrices enter the tree
     size_t Din = 0, nskip = 1;
@@ -385,6 +391,8 @@ public:
         p.kappa = kappa;
         p.disc = akns_disc;
         p.deg = deg0;
+        real_run = want_real && kdv && d_r == rneg;
+        p.real_out = real_run ? 1 : 0;
         cur = 0;
         kappa_run = kappa;
         const int spt = use_leaf ? leaf_spt(deg0) : 0;
@@ -452,14 +460,85 @@ public:
         be.memset0(wexp[0], n0 * sizeof(int));
         cur = 0;
         ne = 4;
+        real_run = false;
         start_n = n0;
         start_d = (size_t)deg0;
         return NFT_SUCCESS;
     }
 
     // ---- product tree (fnft__poly_fmult.c:460-519) ---------------------------------------------
+    // the same tree on real coefficients (nft_real.h): folded transforms of length M = nft_real_len(d)
+    int run_tree_real()
+    {
+        size_t n = start_n, d = start_d;
+        bool y_from_bridge = false, in_pending = false;
+        int zcur = 0, mcur = 0;
+        while (n / batch > 1) {
+            TreeLevel L;
+            L.body_in = body[cur]; L.tail_in = tail[cur]; L.scale_in = scale[cur];
+            L.body_out = body[cur ^ 1]; L.tail_out = tail[cur ^ 1]; L.scale_out = scale[cur ^ 1];
+            L.max2_out = max2[mcur ^ 1];
+            L.max2_in = max2[mcur];
+            L.in_pending = in_pending ? 1 : 0;
+            L.wexp_in = wexp[cur];
+            L.wexp_out = wexp[cur ^ 1];
+            L.plane = plane;
+            L.n_in = (int)n;
+            L.d = (int)d;
+            L.pairs_per_signal = (int)(n / 2 / batch);
+            L.ne = 4;
+            L.kappa = kappa_run;
+            L.dbg = 0;
+            const size_t M = nft_real_len(d);
+            bool ok;
+            if (d <= (size_t)kSchoolMaxDeg) {
+                ok = dispatch_rpair_school(be, L);
+            } else if (M <= (size_t)kRealFusedMaxM) {
+                L.tw = tw_table(M);
+                L.twx = tw_table(4 * M);
+                ok = dispatch_rpair(be, L, (int)M);
+            } else {
+                BigLevel G;
+                std::memset(&G, 0, sizeof(G));
+                G.L = L;
+                G.Y = Y;
+                G.Z = zcur ? Z2 : Z;
+                G.N2 = kRowTree;
+                G.N1 = (int)(M / kRowTree);
+                if (4 * (size_t)G.N1 > (size_t)kMaxTwTable) return NFT_EC_NOT_YET_IMPLEMENTED;
+                G.btw = big_tw(4 * M);   // row twiddle w_{4M}^{(4 k1 - 1) n2}
+                G.rtwist = 1;
+                G.tw1 = tw_table((size_t)G.N1);
+                G.tw2 = tw_table(kRowTree);
+                G.tw1x2 = tw_table((size_t)2 * G.N1);
+                G.twq = tw_table((size_t)4 * G.N1);
+                G.twq2 = (8 * (size_t)G.N1 <= (size_t)kMaxTwTable) ? tw_table((size_t)8 * G.N1) : nullptr;
+                G.y_unscaled = y_from_bridge ? 1 : 0;
+                ok = true;
+                if (!y_from_bridge) ok = dispatch_rcol_fwd(be, G);
+                if (ok) run_mid(be, G);
+                const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= 512;
+                if (ok) ok = next_split ? dispatch_rbridge(be, G) : dispatch_rcol_inv(be, G);
+                zcur ^= 1;
+                y_from_bridge = ok && next_split;
+                const bool last_level = (n / 2 / batch <= 1);
+                if (ok && last_level) be.template run<KFinalizeScales>((int)(n / 2), 1, L);
+                in_pending = !last_level;
+                mcur ^= 1;
+            }
+            if (!ok) return NFT_EC_NOT_YET_IMPLEMENTED;
+            cur ^= 1;
+            n /= 2;
+            d *= 2;
+        }
+        res_deg = D * (size_t)deg0;
+        tree_valid = true;
+        return NFT_SUCCESS;
+    }
+
     int run_tree()
     {
+        if (real_run) return run_tree_real();
         size_t n = start_n;     // matrices at the current level, all signals
         size_t d = start_d;
         bool y_from_bridge = false;
@@ -589,6 +668,7 @@ public:
         E.batch = (int)batch;
         E.ne = ne;
         E.kappa = kappa_run;
+        E.real_layout = real_run ? 1 : 0;
         const long long tot = 4 * (E.deg + 1) * E.batch;
         be.template run<KExportTm>((int)((tot + 255) / 256), 1, E);
     }
@@ -711,6 +791,7 @@ public:
         C.pf_rho = 2.0 * (T[1] + 0.5 * eps_t);          // :199, boundary coefficient 0.5
         C.pf_a = scheme_2A ? -eps_t / deg1 : 0.0;       // :186-195
         C.cstype = 10;
+        C.real_layout = real_run ? 1 : 0;
         return run_chirp_cached(C);
     }
 
@@ -856,6 +937,7 @@ public:
         // sticky bits of every transform since the last read; cleared here (off the transforms' critical path)
         be.memset0(status, 4 * sizeof(int));
         last_warn = (h[0] & 4) ? 1 : 0;            // fnft__misc.c:371-381: not an error
+        if (h[0] & 8) return NFT_EC_INVALID_ARGUMENT;   // real-coefficient path on a potential that is not real
         if (h[0] & 1) return -NFT_EC_OTHER;        // fnft__akns_fscatter.c:122-126 via CHECK_RETCODE
         if (h[0] & 2) return -NFT_EC_DIV_BY_ZERO;  // fnft_nsev.c:850-853 via CHECK_RETCODE
         return NFT_SUCCESS;

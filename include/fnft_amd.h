@@ -496,6 +496,13 @@ FNFT_INT fnft_amd_kdvv_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UIN
                                    fnft_kdv_discretization_t discretization, int device);
 FNFT_INT fnft_amd_kdvv_contspec_device(fnft_amd_plan_t *plan, const void *d_u, void *d_contspec,
                                        const FNFT_REAL *T, const FNFT_REAL *XI, void *stream);
+/* A real potential (the KdV case; with r = -1 every step matrix of src/private/fnft__akns_fscatter.c:116-917 is then a
+ * real polynomial matrix) takes the real-coefficient product tree: folded transforms of half the length, half the
+ * bytes.  mode -1 (default): fnft_amd_kdvv_contspec_device asks the device whether u is real (one small kernel and a
+ * 4-byte read-back: the call waits for the stream once before it enqueues the transform); 1: the caller guarantees a
+ * real u (no check; a non-real sample is reported by fnft_amd_plan_finish as FNFT_EC_INVALID_ARGUMENT); 0: always the
+ * complex path.  The host-pointer entries fnft_kdvv / fnft__kdv_fscatter look at u on the host. */
+FNFT_INT fnft_amd_kdvv_plan_set_real_mode(fnft_amd_plan_t *plan, int mode);
 
 #ifdef __cplusplus
 }

@@ -146,13 +146,15 @@ int emu_nsev_contspec(size_t D, const std::complex<double> *q, const double *T, 
 }
 
 // fnft_kdvv reflection coefficient, host buffers (kdv_disc 0..17)
+// real != 0: the real-coefficient path (nft_real.h; u must be real)
 int emu_kdvv_contspec(size_t D, const std::complex<double> *u, const double *T, size_t M,
-                      std::complex<double> *contspec, const double *XI, int kdv_disc)
+                      std::complex<double> *contspec, const double *XI, int kdv_disc, int real)
 {
     EmuBackend be;
     const int akns = kdv_disc + 1;
     NftPlan<EmuBackend> pl(be, D, M, 1, akns, nft_akns_degree(akns));
     pl.kdv = true;
+    pl.want_real = real != 0;
     int rc = pl.init();
     if (rc != NFT_SUCCESS) { pl.destroy(); return rc; }
     cplx *du = (cplx *)be.alloc(D * sizeof(cplx));

@@ -46,7 +46,7 @@ def emu():
     L.emu_poly_chirpz.argtypes = [C.c_size_t, vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.c_size_t, vp]
     L.emu_nsev_contspec.argtypes = [C.c_size_t, vp, vp, C.c_size_t, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
-    L.emu_kdvv_contspec.argtypes = [C.c_size_t, vp, vp, C.c_size_t, vp, vp, C.c_int]
+    L.emu_kdvv_contspec.argtypes = [C.c_size_t, vp, vp, C.c_size_t, vp, vp, C.c_int, C.c_int]
     L.emu_nsev_discspec.argtypes = [C.c_size_t, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                     C.c_int, C.POINTER(C.c_size_t), vp, vp]
     return L
@@ -158,13 +158,15 @@ def test_nsev_vs_oracle(emu, oracle, D, M, disc, kappa):
 @pytest.mark.parametrize("testcase,D,disc", [("SECH", 256, "2SPLIT4B"), ("SECH", 300, "2SPLIT2A"), ("RECT", 4, "2SPLIT8B"),
                                               ("NEGATIVE_RECT", 4, "2SPLIT2A"), ("SECH", 128, "2SPLIT8B"),
                                               ("SECH", 200, "2SPLIT3A"), ("RECT", 64, "2SPLIT1A")])
-def test_kdvv_vs_oracle(emu, oracle, fixtures, testcase, D, disc):
-    """fnft_kdvv pipeline (general 2x2 tree with r = -1, entries 12/22, -xi grid) in the emulator."""
+@pytest.mark.parametrize("real", [0, 1])
+def test_kdvv_vs_oracle(emu, oracle, fixtures, testcase, D, disc, real):
+    """fnft_kdvv pipeline (general 2x2 tree with r = -1, entries 12/22, -xi grid) in the emulator; real = 1: the
+    real-coefficient path (folded negacyclic transforms, nft_real.h)."""
     from oracle.oracle import KDV_DISC
     u, T, XI, M, exact = S.kdvv_case(fixtures, testcase, D)
     T, XI = np.array(T, np.float64), np.array(XI, np.float64)
     out = np.zeros(M, np.complex128)
-    rc = emu.emu_kdvv_contspec(D, _P(u), _P(T), M, _P(out), _P(XI), KDV_DISC[disc])
+    rc = emu.emu_kdvv_contspec(D, _P(u), _P(T), M, _P(out), _P(XI), KDV_DISC[disc], real)
     assert rc == 0
     rc2, ref = oracle.fnft_kdvv(u, T, M, XI, disc)
     assert rc2 == 0

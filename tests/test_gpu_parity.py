@@ -449,6 +449,79 @@ def test_kdvv_device_batch(capi, oracle):
     plan.close()
 
 
+@pytest.mark.parametrize("D,M,disc", [(4096, 4096, "2SPLIT8B"), (2048, 512, "2SPLIT2A"), (3000, 700, "2SPLIT4A"),
+                                      (8192, 8192, "2SPLIT4B"), (1 << 15, 4096, "2SPLIT8B"), (5000, 333, "2SPLIT5B"),
+                                      (1 << 14, 1000, "2SPLIT1A")])
+def test_kdvv_real_and_complex_tree(capi, oracle, D, M, disc):
+    """The real-coefficient tree (nft_real.h: folded negacyclic transforms; what a real potential gets) and the complex
+    general-form tree on the same real potential: both against the oracle, and against each other.  Sizes cover direct
+    products, single-workgroup pair products (exact and loose transform lengths) and split levels with bridges."""
+    import torch
+    T, XI = [-16.0, 15.0], [-71.0 / 20.0, 79.0 / 20.0]
+    u = 0.8 * S.kdvv_sech(D, T)
+    du = torch.from_numpy(u).cuda()
+    res = {}
+    for mode in (1, 0, -1):
+        plan = capi.KdvvPlan(D, M, batch=1, discretization=disc)
+        assert plan.set_real_mode(mode) == 0
+        out = torch.zeros(M, dtype=torch.complex128, device="cuda")
+        plan.set_launch_timing(True)
+        rc = plan.contspec_device(du.data_ptr(), out.data_ptr(), T, XI)
+        assert rc == 0, capi.last_error()
+        assert plan.finish() == 0
+        torch.cuda.synchronize()
+        names = [n for n, _ in plan.launch_times()]
+        used_real = any(n.startswith(("KRPair", "KRCol", "KRBridge")) for n in names)
+        assert used_real == (mode != 0), (mode, names)   # the default mode finds the potential real
+        res[mode] = out.cpu().numpy()
+        plan.close()
+    rc2, ref = oracle.fnft_kdvv(u, T, M, XI, disc)
+    assert rc2 == 0
+    tol = 1e-9 if disc[6] in "5678" else 2e-11
+    assert S.rel_err(res[1], ref) < tol and S.rel_err(res[0], ref) < tol
+    assert S.rel_err(res[1], res[0]) < tol
+    assert np.array_equal(res[1], res[-1])
+
+
+def test_kdvv_complex_potential_takes_complex_tree(capi, oracle):
+    """A potential with a non-zero imaginary part: the default mode falls back to the complex tree (same result as the
+    oracle, which computes in complex arithmetic like the reference); mode 1 ('the caller guarantees a real u')
+    reports the violation from fnft_amd_plan_finish instead of returning a wrong spectrum."""
+    import torch
+    capi.silence_errors()
+    D, M = 2048, 256
+    T, XI = [-16.0, 15.0], [-3.0, 3.5]
+    u = 0.8 * S.kdvv_sech(D, T) * (1.0 + 0.05j)
+    rc, cs = capi.fnft_kdvv(u, T, M, XI, discretization="2SPLIT4B")
+    assert rc == 0
+    rc2, ref = oracle.fnft_kdvv(u, T, M, XI, "2SPLIT4B")
+    assert rc2 == 0 and S.rel_err(cs, ref) < 2e-11
+    du = torch.from_numpy(u).cuda()
+    out = torch.zeros(M, dtype=torch.complex128, device="cuda")
+    plan = capi.KdvvPlan(D, M, batch=1, discretization="2SPLIT4B")
+    assert plan.contspec_device(du.data_ptr(), out.data_ptr(), T, XI) == 0 and plan.finish() == 0
+    assert S.rel_err(out.cpu().numpy(), ref) < 2e-11
+    plan.set_real_mode(1)
+    assert plan.contspec_device(du.data_ptr(), out.data_ptr(), T, XI) == 0
+    assert plan.finish() == capi.FNFT_EC_INVALID_ARGUMENT
+    plan.close()
+
+
+def test_kdv_fscatter_real_tree_exports_reference_layout(capi, oracle):
+    """fnft__kdv_fscatter on a real potential rides on the real-coefficient tree; the exported transfer matrix is the
+    reference's complex layout (imaginary parts exactly zero)."""
+    T = (-16.0, 15.0)
+    for D, disc in ((4096, "2SPLIT8B"), (1000, "2SPLIT4A")):
+        u = S.kdvv_sech(D, T)
+        eps_t = (T[1] - T[0]) / (D - 1)
+        rc, deg, tm, W = capi.kdv_fscatter(u, eps_t, disc)
+        assert rc == 0, capi.last_error()
+        assert np.all(tm.imag == 0.0)
+        rc2, deg2, ref, W2 = oracle.kdv_fscatter(u, eps_t, disc, normalize=True)
+        assert rc2 == 0 and deg == deg2
+        assert _tm_err(tm, W, ref, W2) < 1e-11
+
+
 def test_kdvv_argument_errors(capi):
     capi.silence_errors()
     u = np.ones(8, np.complex128)
