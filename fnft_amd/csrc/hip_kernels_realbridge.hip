@@ -11,3 +11,4 @@ FA_INST(KRBridge<64>)
 FA_INST(KRBridge<128>)
 FA_INST(KRBridge<256>)
 FA_INST(KRBridge<512>)
+FA_INST(KMidGen)

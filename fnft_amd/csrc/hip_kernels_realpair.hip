@@ -3,6 +3,10 @@
 #include "hip_be.h"
 
 FA_INST(KRealCheck)
+FA_INST(KRCoeffsStrang<6, false>)
+FA_INST(KRCoeffsStrang<6, true>)
+FA_INST(KRCoeffsStrang<8, false>)
+FA_INST(KRCoeffsStrang<8, true>)
 FA_INST(KRPairSchool<1>)
 FA_INST(KRPairSchool<2>)
 FA_INST(KRPairSchool<3>)

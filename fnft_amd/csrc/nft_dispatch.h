@@ -485,10 +485,17 @@ template <bool DIRECT> struct KMidSym {
 #ifndef FA_MID_SYM
 #define FA_MID_SYM 1   // 0: the generic-IO row kernel (KMid<2>) for the symmetric form as well
 #endif
+#ifndef FA_MID_GEN
+#define FA_MID_GEN 1   // 0: the generic-IO row kernel KMid<4> for the general form
+#endif
+template <class BE> void run_mid_gen(BE &be, int g, const BigLevel &G);
 template <class BE> void run_mid(BE &be, const BigLevel &G)
 {
     const int g = (G.L.n_in / 2) * G.N1;
-    if (G.L.ne == 4) be.template run<KMid<4>>(g, 1, G);
+    if (G.L.ne == 4) {
+        if constexpr (FA_MID_GEN) run_mid_gen(be, g, G);
+        else be.template run<KMid<4>>(g, 1, G);
+    }
     else if constexpr (!FA_MID_SYM) be.template run<KMid<2>>(g, 1, G);
     else if (G.y_direct) be.template run<KMidSym<true>>(g, 1, G);
     else be.template run<KMidSym<false>>(g, 1, G);
@@ -689,3 +696,35 @@ struct KRealCheck {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_real_check(p); }
 };
+template <int ORDER, bool BFIRST> struct KRCoeffsStrang {
+    using Params = CoeffParams;
+    static constexpr int THREADS = 64;
+    static constexpr size_t lds_bytes() { return (size_t)64 * RStrangCfg<ORDER, BFIRST>::DEG * sizeof(double); }
+    static FA_DEV void body(const Params &p) { body_rcoeffs_strang<ORDER, BFIRST>(p); }
+};
+// akns_disc 13 (2SPLIT6A), 14 (6B), 17 (8A), 18 (8B)
+template <class BE> bool dispatch_rcoeffs_strang(BE &be, const CoeffParams &p)
+{
+    const long long n = (long long)p.batch * p.Dpad;
+    const int g = (int)((n + 63) / 64);
+    switch (p.disc) {
+    case 13: be.template run<KRCoeffsStrang<6, false>>(g, 1, p); return true;
+    case 14: be.template run<KRCoeffsStrang<6, true>>(g, 1, p); return true;
+    case 17: be.template run<KRCoeffsStrang<8, false>>(g, 1, p); return true;
+    case 18: be.template run<KRCoeffsStrang<8, true>>(g, 1, p); return true;
+    default: return false;
+    }
+}
+// general 4-entry row kernel with back-to-back loads and pair-interleaved transforms (body_mid_gen, nft_real.h)
+#ifndef FA_MIDGEN_R
+#define FA_MIDGEN_R 4
+#endif
+struct KMidGen {
+    using Params = BigLevel;
+    static constexpr int R = FA_MIDGEN_R;
+    static constexpr int THREADS = kRowTree / R;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_mid_gen<kRowTree, R>(p); }
+};
+template <class BE> void run_mid_gen(BE &be, int g, const BigLevel &G) { be.template run<KMidGen>(g, 1, G); }

@@ -417,7 +417,10 @@ public:
             if (!dispatch_leaf(be, lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
             return NFT_SUCCESS;
         }
-        if (prog_ptr != nullptr) {
+        if (real_run && dispatch_rcoeffs_strang(be, p)) {
+            // even-order splitting schemes on the real path: composed from their elementary factors (nft_real.h)
+            ne = 4;
+        } else if (prog_ptr != nullptr) {
             // schemes of order 5..8: generated coefficient program; the symmetric form can start at
             // level 0 because every level is an FFT level (deg0 > kSchoolMaxDeg)
             ne = (use_sym && d_r == nullptr) ? 2 : 4;
@@ -617,7 +620,7 @@ public:
                 G.y_unscaled = y_from_bridge ? 1 : 0;
                 // first split level: a length-4 column transform of two non-zero rows is done by the row
                 // kernel on the fly (saves the column launch and its 32 + 64 MB)
-                G.y_direct = (use_direct4 && !y_from_bridge && G.N1 == 4 && N == 2 * d && dbg_flags == 0) ? 1 : 0;
+                G.y_direct = (use_direct4 && !y_from_bridge && G.N1 == 4 && N == 2 * d && dbg_flags == 0 && (ne == 2 || !FA_MID_GEN)) ? 1 : 0;
                 G.stagger = (n / 2 * (size_t)G.N1 == 512) ? tune_stagger : 0;   // exactly one round of workgroups
                 G.stamps = (dbg_stamps && split_idx == stamp_level) ? dbg_stamps : nullptr;
                 split_idx++;

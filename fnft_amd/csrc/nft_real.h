@@ -410,3 +410,303 @@ FA_DEV void body_real_check(const RealCheckParams &P)
         bad = bad || (P.q[i].y != 0.0);
     if (bad) fa_atomic_or_i32(P.flag, 1);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Per-sample coefficients of the even-order splitting schemes 2SPLIT6A/6B/8A/8B for real q, r
+// (fnft__akns_fscatter.c:567-641, 795-912), composed from their elementary factors instead of the reference's
+// expanded coefficient formulas (or the monomial program of body_coeffs_prog): the scheme is
+//     sum_{n=1..T} w_n Psi_n,   T = ORDER/2,   w_n = n^(2(T-1)) / prod_{m != n} (n^2 - m^2),
+//     Psi_n = X(1/2n) [Y(1/n) X(1/n)]^(n-1) Y(1/n) X(1/2n)     (n Strang steps),
+// X = B, Y = A for the "B" schemes and the other way round for the "A" schemes, with A(a) = diag(1, z^(a*deg)) and
+// B(b) = expm([[0,q],[r,0]] b eps_t) = [[c, q s],[r s, c]] (:46-59).  Psi_n is a polynomial in u = z^(deg/n) (B first) or
+// z^(deg/2n) (A first); a factor is one shift of the second column or one 2x2 column mix.  One lane per sample, 64-lane
+// workgroups, coefficients staged through LDS so that lanes write consecutive doubles.
+// ---------------------------------------------------------------------------------------------
+struct RStep { double c, qs, rs; };
+// expm([[0,q],[r,0]] h) for real q, r (zero_freq_step restricted to the real axis: -q r >= 0 gives cos / sinc,
+// -q r < 0 the hyperbolic pair; fnft__misc.c:306-314 for the sinc)
+FA_DEV RStep rzero_freq_step(double h, double q, double r)
+{
+    const double s2 = -(q * r);
+    const double y = h * sqrt(fabs(s2));
+    double c, snc;
+    if (s2 >= 0.0) {
+        double sn;
+        fa_sincos(y, &sn, &c);
+        if (y >= 1.0e-8) snc = sn / y;
+        else fa_sincos(y * 0.57735026918962576451, &sn, &snc);
+    } else {
+        const double ep = exp(y), em = 1.0 / ep;
+        c = 0.5 * (ep + em);
+        if (y >= 1.0e-8) snc = 0.5 * (ep - em) / y;
+        else { const double e2 = exp(y * 0.57735026918962576451); snc = 0.5 * (e2 + 1.0 / e2); }
+    }
+    RStep e;
+    e.c = c;
+    e.qs = q * (h * snc);
+    e.rs = r * (h * snc);
+    return e;
+}
+template <int NU> struct RPolyMat {
+    double m[2][2][NU + 1];   // ascending powers of u
+    FA_DEV void set(const RStep &b)
+    {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int k = 0; k <= NU; k++) m[i][j][k] = 0.0;
+        m[0][0][0] = b.c; m[0][1][0] = b.qs; m[1][0][0] = b.rs; m[1][1][0] = b.c;
+    }
+    FA_DEV void identity()
+    {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int k = 0; k <= NU; k++) m[i][j][k] = 0.0;
+        m[0][0][0] = 1.0; m[1][1][0] = 1.0;
+    }
+    // * diag(1, u^K): the second column moves up K powers
+    template <int K> FA_DEV void shift()
+    {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int k = NU; k >= K; k--) m[i][1][k] = m[i][1][k - K];
+#pragma unroll
+            for (int k = 0; k < K; k++) m[i][1][k] = 0.0;
+        }
+    }
+    // * [[c, qs],[rs, c]]
+    FA_DEV void mix(const RStep &b)
+    {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int k = 0; k <= NU; k++) {
+                const double x0 = m[i][0][k], x1 = m[i][1][k];
+                m[i][0][k] = fma(x1, b.rs, x0 * b.c);
+                m[i][1][k] = fma(x0, b.qs, x1 * b.c);
+            }
+    }
+};
+// Psi_n accumulated into P[e][k] (k: highest power of z first, as stored), weight w
+template <int DEG, int NS, bool BFIRST> FA_DEV void rstrang_term(double eps_t, double q, double r, double w, double (&P)[4][DEG + 1])
+{
+    constexpr int NU = BFIRST ? NS : 2 * NS;
+    constexpr int G = DEG / NU;   // powers of z per power of u
+    const RStep full = rzero_freq_step(eps_t / (double)NS, q, r);
+    RPolyMat<NU> M;
+    if constexpr (BFIRST) {
+        const RStep half = rzero_freq_step(eps_t / (double)(2 * NS), q, r);
+        M.set(half);
+#pragma unroll
+        for (int i = 1; i <= NS; i++) {
+            M.template shift<1>();
+            M.mix(i < NS ? full : half);
+        }
+    } else {
+        M.identity();
+        M.template shift<1>();
+#pragma unroll
+        for (int i = 1; i <= NS; i++) {
+            M.mix(full);
+            if (i < NS) M.template shift<2>();
+            else M.template shift<1>();
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int k = 0; k <= NU; k++) P[e][DEG - k * G] = fma(w, M.m[e >> 1][e & 1][k], P[e][DEG - k * G]);
+}
+template <int ORDER, bool BFIRST> struct RStrangCfg {
+    static constexpr int T = ORDER / 2;
+    static constexpr int DEG = (T == 3 ? 6 : 12) * (BFIRST ? 1 : 2);
+};
+template <int ORDER, bool BFIRST> FA_DEV void body_rcoeffs_strang(const CoeffParams &P)
+{
+    constexpr int T = RStrangCfg<ORDER, BFIRST>::T, DEG = RStrangCfg<ORDER, BFIRST>::DEG;
+    FA_LDS_DECL
+    double *stage = (double *)FA_LDS_PTR;   // 64 x DEG
+    const int lane = FA_TID;
+    const long long gid0 = (long long)FA_BID * FA_BDIM, gid = gid0 + lane;
+    const long long n = (long long)P.batch * P.Dpad;
+    const bool act = gid < n;
+    const int b = act ? (int)(gid / P.Dpad) : 0, j = act ? (int)(gid % P.Dpad) : 0;
+    double C[4][DEG + 1];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int k = 0; k <= DEG; k++) C[e][k] = 0.0;
+    if (act && j < P.D) {
+        const size_t src = (size_t)b * P.D + (size_t)(P.D - 1 - j);
+        const cplx qc = P.q[src];
+        const cplx rc = P.r ? P.r[src] : cmake(-qc.x * (double)P.kappa, 0.0);
+        if (qc.y != 0.0 || rc.y != 0.0) fa_atomic_or_i32(P.status, 8);
+        const double q = qc.x, r = rc.x;
+        // w_n = n^(2(T-1)) / prod_{m != n} (n^2 - m^2)
+        if constexpr (T == 3) {
+            rstrang_term<DEG, 1, BFIRST>(P.eps_t, q, r, 1.0 / 24.0, C);
+            rstrang_term<DEG, 2, BFIRST>(P.eps_t, q, r, -16.0 / 15.0, C);
+            rstrang_term<DEG, 3, BFIRST>(P.eps_t, q, r, 81.0 / 40.0, C);
+        } else {
+            rstrang_term<DEG, 1, BFIRST>(P.eps_t, q, r, -1.0 / 360.0, C);
+            rstrang_term<DEG, 2, BFIRST>(P.eps_t, q, r, 16.0 / 45.0, C);
+            rstrang_term<DEG, 3, BFIRST>(P.eps_t, q, r, -729.0 / 280.0, C);
+            rstrang_term<DEG, 4, BFIRST>(P.eps_t, q, r, 1024.0 / 315.0, C);
+        }
+    } else if (act) {   // identity pad z^deg * I (fnft__poly_fmult.c:422-438)
+        C[0][0] = 1.0;
+        C[3][0] = 1.0;
+    }
+    const long long nact = (n - gid0 < 64) ? n - gid0 : 64;
+    double *rb = (double *)P.body, *rt = (double *)P.tail;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) stage[lane * DEG + ((k + lane) % DEG)] = C[e][k];
+        if (act) rt[(size_t)e * n + gid] = C[e][DEG];
+        FA_SYNC();
+        double *out0 = rb + (size_t)e * P.plane + (size_t)gid0 * DEG;
+        for (int m = lane; m < (int)nact * DEG; m += 64) {
+            const int t2 = m / DEG, k2 = m - t2 * DEG;
+            out0[m] = stage[t2 * DEG + ((k2 + t2) % DEG)];
+        }
+        FA_SYNC();
+    }
+    if (act) {
+        P.scale[gid] = 1.0;
+        P.wexp[gid] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row step of a split level in the general 4-entry form, written like body_mid_sym (nft_kernels.h) for memory-level
+// parallelism: the four rows of the left factor are requested back to back, the rows of the right factor's two columns
+// from inside the left factor's transforms (fft_wg2 hooks), the transforms run in pairs
+//     (A00, A01) (A10, A11) (B00, B10) -> C00 = A00 B00 + A01 B10, C10 = A10 B00 + A11 B10 -> inverse pair, store,
+//     (B01, B11) -> C01, C11 -> inverse pair, store,
+// and every barrier is an LDS-only one.  Serves the complex general form (Y rows; with spectral doubling the even rows
+// come from the previous level's Z) and the real-coefficient path (BigLevel::rtwist).  8 + 4 transforms as
+// fnft__poly_fmult.c:239-328.
+// ---------------------------------------------------------------------------------------------
+template <int N2, int R> struct MidColLoader {
+    const cplx *p0, *p1;
+    int rows, row, v;
+    cplx (&x0)[R];
+    cplx (&x1)[R];
+    FA_DEV void operator()(int k) const
+    {
+#pragma unroll
+        for (int i = 0; i < R; i++)
+            if (i / 2 == k) {
+                const size_t o = yz_index(rows, N2, row, v + (N2 / R) * i);
+                x0[i] = p0[o];
+                x1[i] = p1[o];
+            }
+    }
+};
+template <int N2, int R> FA_DEV void body_mid_gen(const BigLevel &G)
+{
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int v = FA_TID;
+    const int n_in = L.n_in, n_out = n_in / 2;
+    const long long P = FA_BID / G.N1;
+    const int k1 = FA_BID % G.N1;
+    const long long mA = 2 * P, mB = 2 * P + 1;
+    const bool split = G.y_split != 0;
+    const int rows = split ? G.N1 / 2 : G.N1;
+    const int row = split ? (k1 >> 1) : k1;
+    const cplx *base = split ? ((k1 & 1) ? G.Y : G.Zprev) : G.Y;
+    const size_t blk = (size_t)rows * N2;
+    // entry e of matrix m: polynomial e*n_in + m
+    const cplx *pA = base + (size_t)mA * blk, *pB = base + (size_t)mB * blk;
+    const size_t estr = (size_t)n_in * blk;
+    cplx a00[R], a01[R], a10[R], a11[R], b0[R], b1[R], c0[R], c1[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const size_t o = yz_index(rows, N2, row, v + (N2 / R) * i);
+        a00[i] = pA[o]; a01[i] = pA[estr + o]; a10[i] = pA[2 * estr + o]; a11[i] = pA[3 * estr + o];
+    }
+    MidColLoader<N2, R> ld0{pB, pB + 2 * estr, rows, row, v, b0, b1};              // column 0 of B: B00, B10
+    MidColLoader<N2, R> ld1{pB + estr, pB + 3 * estr, rows, row, v, c0, c1};      // column 1 of B: B01, B11
+    // ---- bookkeeping of the level (once per pair) and the factors every polynomial shares ----------------
+    const int pendA = level_in_pending_exp(L, mA), pendB = level_in_pending_exp(L, mB);   // workgroup-uniform
+    if (k1 == 0 && v == 0) L.wexp_out[P] = L.wexp_in[mA] + pendA + L.wexp_in[mB] + pendB;
+    if (k1 == 0 && v < kMax2Slots) L.max2_out[(size_t)P * kMax2Slots + v] = 0u;
+    const bool rescale = G.y_unscaled != 0;
+    const double scA = !rescale ? 1.0 : (L.in_pending ? pow2i(-pendA) : L.scale_in[mA]);
+    const double scB = !rescale ? 1.0 : (L.in_pending ? pow2i(-pendB) : L.scale_in[mB]);
+    const cplx wbase = big_twiddle(G.btw, row_tw_index(G, k1, v));
+    cplx wu[R];
+    wu[0] = cmake(1.0, 0.0);
+#pragma unroll
+    for (int i = 1; i < R; i++) {
+        const cplx w = big_twiddle(G.btw, row_tw_index(G, k1, (N2 / R) * i));
+        wu[i] = cmake(fa_uniform(w.x), fa_uniform(w.y));
+    }
+    const cplx *tw = G.tw2;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx wA = ((i == 0) ? wbase : wbase * wu[i]) * scA;
+        a00[i] = a00[i] * wA; a01[i] = a01[i] * wA;
+    }
+    fft_wg2<N2, R, 1, -1, true>(a00, a01, lds, v, 0, tw, ld0);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx wA = ((i == 0) ? wbase : wbase * wu[i]) * scA;
+        a10[i] = a10[i] * wA; a11[i] = a11[i] * wA;
+    }
+    fft_wg2<N2, R, 1, -1, true>(a10, a11, lds, v, 0, tw, ld1);
+    cplx *dZ = G.Z + (size_t)P * G.N1 * N2;
+    const size_t zstr = (size_t)n_out * G.N1 * N2;
+    const cplx wb = wbase * (1.0 / (double)N2);
+    // ---- column 0 ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx wB = ((i == 0) ? wbase : wbase * wu[i]) * scB;
+        b0[i] = b0[i] * wB; b1[i] = b1[i] * wB;
+    }
+    fft_wg2<N2, R, 1, -1, true>(b0, b1, lds, v, 0, tw);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx x0 = b0[i], x1 = b1[i];
+        b0[i] = cfma(a01[i], x1, a00[i] * x0);
+        b1[i] = cfma(a11[i], x1, a10[i] * x0);
+    }
+    fft_wg2<N2, R, 1, +1, true>(b0, b1, lds, v, 0, tw);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx w = cconj((i == 0) ? wb : wb * wu[i]);
+        const size_t o = yz_index(G.N1, N2, k1, v + (N2 / R) * i);
+        dZ[o] = b0[i] * w;                // C00
+        dZ[2 * zstr + o] = b1[i] * w;     // C10
+    }
+    // ---- column 1 ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx wB = ((i == 0) ? wbase : wbase * wu[i]) * scB;
+        c0[i] = c0[i] * wB; c1[i] = c1[i] * wB;
+    }
+    fft_wg2<N2, R, 1, -1, true>(c0, c1, lds, v, 0, tw);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx x0 = c0[i], x1 = c1[i];
+        c0[i] = cfma(a01[i], x1, a00[i] * x0);
+        c1[i] = cfma(a11[i], x1, a10[i] * x0);
+    }
+    fft_wg2<N2, R, 1, +1, true>(c0, c1, lds, v, 0, tw);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const cplx w = cconj((i == 0) ? wb : wb * wu[i]);
+        const size_t o = yz_index(G.N1, N2, k1, v + (N2 / R) * i);
+        dZ[zstr + o] = c0[i] * w;         // C01
+        dZ[3 * zstr + o] = c1[i] * w;     // C11
+    }
+}
