@@ -220,6 +220,10 @@ template <int N, int R, int B, int SIGN, bool DB, int NCUR, int S, bool TWC = fa
                     t[9] = t[9] * (w1 * w8);   t[10] = t[10] * (w2 * w8);  t[11] = t[11] * (w3 * w8);
                     t[12] = t[12] * (w4 * w8); t[13] = t[13] * (w5 * w8);  t[14] = t[14] * (w6 * w8);
                     t[15] = t[15] * (w7 * w8);
+                } else if constexpr (TWC && r == 4) {
+                    const cplx w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
+                    const cplx w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
+                    t[1] = t[1] * w1;  t[2] = t[2] * w2;  t[3] = t[3] * (w1 * w2);
                 } else {
 #pragma unroll
                     for (int k = 1; k < r; k++) t[k] = t[k] * tw_dir<SIGN>(tw[(size_t)(p * k) * S]);
@@ -283,7 +287,8 @@ template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2P
     static constexpr int J = R / r;
     static constexpr bool last = (NCUR == r);
     // one shared, prefetched twiddle set per pass: radix-8 passes of one butterfly per lane with the table in L2
-    static constexpr bool kShared = TWC && r == 8 && J == 1 && !last;
+    // (radix 4: w and w^2, the third factor by multiplication)
+    static constexpr bool kShared = TWC && (r == 8 || r == 4) && J == 1 && !last;
 
     static FA_DEV TwSet8 load_tw(int v, const cplx *__restrict__ tw)
     {
@@ -292,7 +297,8 @@ template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2P
             const int p = v / S;
             t.w1 = tw_dir<SIGN>(tw[(size_t)p * S]);
             t.w2 = tw_dir<SIGN>(tw[(size_t)(2 * p) * S]);
-            t.w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+            if constexpr (r == 8) t.w4 = tw_dir<SIGN>(tw[(size_t)(4 * p) * S]);
+            else t.w4 = cmake(1.0, 0.0);
         } else {
             t.w1 = t.w2 = t.w4 = cmake(1.0, 0.0);
         }
@@ -312,7 +318,11 @@ template <int N, int R, int B, int SIGN, int NCUR, int S, bool TWC> struct Fft2P
             for (int k = 0; k < r; k++) t[k] = x[j + J * k];
             RegDft<r, SIGN>::run(t);
             if constexpr (!last) {
-                if constexpr (kShared) {
+                if constexpr (kShared && r == 4) {
+                    t[1] = t[1] * ts.w1;
+                    t[2] = t[2] * ts.w2;
+                    t[3] = t[3] * (ts.w1 * ts.w2);
+                } else if constexpr (kShared) {
                     t[4] = t[4] * ts.w4; t[5] = t[5] * ts.w4; t[6] = t[6] * ts.w4; t[7] = t[7] * ts.w4;
                     t[1] = t[1] * ts.w1; t[5] = t[5] * ts.w1;
                     t[2] = t[2] * ts.w2; t[6] = t[6] * ts.w2;

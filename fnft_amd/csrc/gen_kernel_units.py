@@ -33,7 +33,7 @@ groups["bridge"] = ["KColBridge<%d>" % n for n in N1_BR] + ["KColBridge2<%d>" % 
 groups["realpair"] = ["KRealCheck", "KRCoeffsStrang<6, false>", "KRCoeffsStrang<6, true>", "KRCoeffsStrang<8, false>", "KRCoeffsStrang<8, true>"] + ["KRPairSchool<%d>" % d for d in (1, 2, 3)] + ["KRPair<%d>" % m for m in (4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048)]
 N1_RCOL = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 groups["realcol"] = ["KRColFwd<%d>" % n for n in N1_RCOL] + ["KRColInv<%d>" % n for n in N1_RCOL]
-groups["realbridge"] = ["KRBridge<%d>" % n for n in N1_BR] + ["KMidGen"]
+groups["realbridge"] = ["KRBridge<%d>" % n for n in N1_BR + [1024]] + ["KMidGen<1024>", "KMidGen<2048>"]
 groups["chirpa"] = ["KChirpRows"] + ["KChirpColFwd<%d, false>" % n for n in N1_CHIRP] + ["KChirpColFwd<%d, true>" % n for n in N1_CHIRP]
 groups["chirpb"] = (["KChirpColInv<%d, false, false>" % n for n in N1_CHIRP] + ["KChirpColInv<%d, true, false>" % n for n in N1_CHIRP]
                     + ["KChirpColInv<%d, false, true>" % n for n in N1_CHIRP])

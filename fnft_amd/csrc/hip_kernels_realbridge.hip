@@ -11,4 +11,6 @@ FA_INST(KRBridge<64>)
 FA_INST(KRBridge<128>)
 FA_INST(KRBridge<256>)
 FA_INST(KRBridge<512>)
-FA_INST(KMidGen)
+FA_INST(KRBridge<1024>)
+FA_INST(KMidGen<1024>)
+FA_INST(KMidGen<2048>)

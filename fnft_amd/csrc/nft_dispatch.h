@@ -630,6 +630,7 @@ template <int N1> struct RBridgeCfg {
     static constexpr bool DB = false;
     static constexpr size_t lds_bytes() { return (N1 > R) ? (size_t)2 * N1 * BC * sizeof(cplx) : 0; }
 };
+constexpr int kRBridgeMaxN1 = 1024;
 template <int N1> struct KRBridge {
     using Params = BigLevel;
     using C = RBridgeCfg<N1>;
@@ -685,7 +686,7 @@ template <class BE> bool dispatch_rbridge(BE &be, const BigLevel &G)
     const int polys = 4 * (G.L.n_in / 2);
     switch (G.N1) {
 #define X(n1) case n1: be.template run<KRBridge<n1>>(G.N2 / RBridgeCfg<n1>::BC, polys, G); return true;
-        FA_FOR_EACH_BRIDGE_N1(X)
+        FA_FOR_EACH_BRIDGE_N1(X) X(1024)
 #undef X
     default: return false;
     }
@@ -719,12 +720,24 @@ template <class BE> bool dispatch_rcoeffs_strang(BE &be, const CoeffParams &p)
 #ifndef FA_MIDGEN_R
 #define FA_MIDGEN_R 4
 #endif
-struct KMidGen {
+// rows of 1024 points (256 lanes, two workgroups per CU) beat rows of 2048 (512 lanes, one per CU): cfg 5 row kernel
+// 147 -> 111 us; 2048 only where the column transform would otherwise exceed the instantiated lengths
+#ifndef FA_ROW_GEN
+#define FA_ROW_GEN 1024
+#endif
+constexpr int kRowGen = FA_ROW_GEN;
+constexpr int kRowGenMaxN1 = 4096;
+inline int row_len_gen(size_t len) { return (len / (size_t)kRowGen <= (size_t)kRowGenMaxN1) ? kRowGen : kRowTree; }
+template <int N2> struct KMidGen {
     using Params = BigLevel;
     static constexpr int R = FA_MIDGEN_R;
-    static constexpr int THREADS = kRowTree / R;
+    static constexpr int THREADS = N2 / R;
     static constexpr int MIN_WAVES = 2;
-    static constexpr size_t lds_bytes() { return (size_t)2 * kRowTree * sizeof(cplx); }
-    static FA_DEV void body(const Params &p) { body_mid_gen<kRowTree, R>(p); }
+    static constexpr size_t lds_bytes() { return (size_t)2 * N2 * sizeof(cplx); }
+    static FA_DEV void body(const Params &p) { body_mid_gen<N2, R>(p); }
 };
-template <class BE> void run_mid_gen(BE &be, int g, const BigLevel &G) { be.template run<KMidGen>(g, 1, G); }
+template <class BE> void run_mid_gen(BE &be, int g, const BigLevel &G)
+{
+    if (G.N2 == kRowGen) be.template run<KMidGen<kRowGen>>(g, 1, G);
+    else be.template run<KMidGen<kRowTree>>(g, 1, G);
+}

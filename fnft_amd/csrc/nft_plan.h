@@ -506,13 +506,13 @@ public:
                 G.L = L;
                 G.Y = Y;
                 G.Z = zcur ? Z2 : Z;
-                G.N2 = kRowTree;
-                G.N1 = (int)(M / kRowTree);
+                G.N2 = row_len_gen(M);
+                G.N1 = (int)(M / (size_t)G.N2);
                 if (4 * (size_t)G.N1 > (size_t)kMaxTwTable) return NFT_EC_NOT_YET_IMPLEMENTED;
                 G.btw = big_tw(4 * M);   // row twiddle w_{4M}^{(4 k1 - 1) n2}
                 G.rtwist = 1;
                 G.tw1 = tw_table((size_t)G.N1);
-                G.tw2 = tw_table(kRowTree);
+                G.tw2 = tw_table((size_t)G.N2);
                 G.tw1x2 = tw_table((size_t)2 * G.N1);
                 G.twq = tw_table((size_t)4 * G.N1);
                 G.twq2 = (8 * (size_t)G.N1 <= (size_t)kMaxTwTable) ? tw_table((size_t)8 * G.N1) : nullptr;
@@ -520,7 +520,8 @@ public:
                 ok = true;
                 if (!y_from_bridge) ok = dispatch_rcol_fwd(be, G);
                 if (ok) run_mid(be, G);
-                const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= 512;
+                const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= kRBridgeMaxN1
+                                        && row_len_gen(2 * M) == G.N2;
                 if (ok) ok = next_split ? dispatch_rbridge(be, G) : dispatch_rcol_inv(be, G);
                 zcur ^= 1;
                 y_from_bridge = ok && next_split;
@@ -610,11 +611,11 @@ public:
                 G.Z = zcur ? Z2 : Z;
                 G.Zprev = zcur ? Z : Z2;
                 G.y_split = y_split ? 1 : 0;
-                G.N2 = kRowTree;
-                G.N1 = (int)(N / kRowTree);
+                G.N2 = (ne == 4 && FA_MID_GEN) ? row_len_gen(N) : kRowTree;
+                G.N1 = (int)(N / (size_t)G.N2);
                 G.btw = big_tw(N);
                 G.tw1 = (G.N1 >= 2) ? tw_table((size_t)G.N1) : nullptr;
-                G.tw2 = tw_table(kRowTree);
+                G.tw2 = tw_table((size_t)G.N2);
                 G.tw1x2 = tw_table((size_t)2 * G.N1);
                 G.btw2 = big_tw(2 * N);
                 G.y_unscaled = y_from_bridge ? 1 : 0;
@@ -630,7 +631,8 @@ public:
                 // bridge straight into the next level's column step when that level is split too
                 const bool can_double = use_doubling;   // N = 2d and N > 2d alike (body_col_bridge2)
                 const bool next_split = use_bridge && (n / 2 / batch > 1) && G.N1 <= (can_double ? 4096 : 512)
-                                        && nft_product_len(2 * d) == 2 * N;
+                                        && nft_product_len(2 * d) == 2 * N
+                                        && ((ne == 4 && FA_MID_GEN) ? row_len_gen(2 * N) : kRowTree) == G.N2;
                 const bool doubling = next_split && can_double;
                 if (ok) {
                     if (doubling) ok = dispatch_col_bridge2(be, G);
