@@ -78,9 +78,9 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
             kind, lv = "fused levels " + n, int(re.findall(r"\d+", n)[-1])
         elif base in ("KPairSchool", "KPairFft", "KRPairSchool", "KRPair"):
             kind, lv = "single-launch levels", 1
-        elif base in ("KMid", "KMidSym"):
+        elif base in ("KMid", "KMidSym", "KMidGen"):
             kind, lv = "split levels", 1
-        elif base in ("KColFwd", "KRColFwd"):
+        elif base in ("KColFwd", "KRColFwd", "KR3ColFwd"):
             kind, lv = "split levels", 0
         elif base == "KRealCheck":
             kind, lv = "leaf", 0

@@ -34,6 +34,9 @@ groups["realpair"] = ["KRealCheck", "KRCoeffsStrang<6, false>", "KRCoeffsStrang<
 N1_RCOL = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 groups["realcol"] = ["KRColFwd<%d>" % n for n in N1_RCOL] + ["KRColInv<%d>" % n for n in N1_RCOL]
 groups["realbridge"] = ["KRBridge<%d>" % n for n in N1_BR + [1024]] + ["KMidGen<1024>", "KMidGen<2048>"]
+K3 = [1, 2, 4, 8, 16, 32, 64, 128, 256]
+groups["real3col"] = ["KR3ColFwd<%d>" % k for k in K3 + [512]] + ["KR3ColInv<%d>" % k for k in K3 + [512]]
+groups["real3bridge"] = ["KR3Bridge<%d>" % k for k in K3]
 groups["chirpa"] = ["KChirpRows"] + ["KChirpColFwd<%d, false>" % n for n in N1_CHIRP] + ["KChirpColFwd<%d, true>" % n for n in N1_CHIRP]
 groups["chirpb"] = (["KChirpColInv<%d, false, false>" % n for n in N1_CHIRP] + ["KChirpColInv<%d, true, false>" % n for n in N1_CHIRP]
                     + ["KChirpColInv<%d, false, true>" % n for n in N1_CHIRP])

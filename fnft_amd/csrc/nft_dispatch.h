@@ -741,3 +741,69 @@ template <class BE> void run_mid_gen(BE &be, int g, const BigLevel &G)
     if (G.N2 == kRowGen) be.template run<KMidGen<kRowGen>>(g, 1, G);
     else be.template run<KMidGen<kRowTree>>(g, 1, G);
 }
+
+// ---- column kernels of length N1 = 3*K (nft_real.h) --------------------------------------------------
+template <int K> struct R3Cfg {
+    static constexpr int R = (K < 4) ? K : 4;
+    static constexpr int THREADS = (K >= 256) ? 512 : 256;
+    static constexpr int BC = THREADS / (K / R);
+    static constexpr size_t lds_col() { return (K > R) ? (size_t)K * BC * sizeof(cplx) : 0; }
+    static constexpr size_t lds_bridge() { return (size_t)2 * K * BC * sizeof(cplx); }   // 2K points, 2R per lane: always > 2R? (K >= R)
+};
+template <int K> struct KR3ColFwd {
+    using Params = BigLevel;
+    using C = R3Cfg<K>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes() { return C::lds_col(); }
+    static FA_DEV void body(const Params &p) { body_r3col_fwd<K, C::R, C::BC>(p); }
+};
+template <int K> struct KR3ColInv {
+    using Params = BigLevel;
+    using C = R3Cfg<K>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes() { return C::lds_col(); }
+    static FA_DEV void body(const Params &p) { body_r3col_inv<K, C::R, C::BC>(p); }
+};
+template <int K> struct KR3Bridge {
+    using Params = BigLevel;
+    using C = R3Cfg<K>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes() { return (K > C::R) ? C::lds_bridge() : 0; }
+    static FA_DEV void body(const Params &p) { body_r3bridge<K, C::R, C::BC>(p); }
+};
+constexpr int kR3MaxK = 512;         // column length up to 1536
+constexpr int kR3BridgeMaxK = 256;   // bridges up to 768 -> 1536
+#define FA_FOR_EACH_R3_K(X) X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256)
+template <class BE> bool dispatch_r3col_fwd(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * G.L.n_in;
+    switch (G.N1 / 3) {
+#define X(k) case k: be.template run<KR3ColFwd<k>>(G.N2 / R3Cfg<k>::BC, polys, G); return true;
+        FA_FOR_EACH_R3_K(X) X(512)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_r3col_inv(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * (G.L.n_in / 2);
+    switch (G.N1 / 3) {
+#define X(k) case k: be.template run<KR3ColInv<k>>(G.N2 / R3Cfg<k>::BC, polys, G); return true;
+        FA_FOR_EACH_R3_K(X) X(512)
+#undef X
+    default: return false;
+    }
+}
+template <class BE> bool dispatch_r3bridge(BE &be, const BigLevel &G)
+{
+    const int polys = 4 * (G.L.n_in / 2);
+    switch (G.N1 / 3) {
+#define X(k) case k: be.template run<KR3Bridge<k>>(G.N2 / R3Cfg<k>::BC, polys, G); return true;
+        FA_FOR_EACH_R3_K(X)
+#undef X
+    default: return false;
+    }
+}

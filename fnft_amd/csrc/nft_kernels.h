@@ -1344,6 +1344,9 @@ struct BigLevel {
     // twq / twq2: exp(-2 pi i j/(4 N1)) and exp(-2 pi i j/(8 N1)) for the column kernels
     int rtwist = 0;
     const cplx *twq = nullptr, *twq2 = nullptr;
+    // column length N1 = 3*K (body_r3*): tables exp(-2 pi i j/N1) and exp(-2 pi i j/(2 N1)); tw1 / tw1x2 then belong to K, 2K
+    const cplx *tw3 = nullptr, *tw3x2 = nullptr;
+    unsigned long long row_mod = 0;   // rtwist: 4*N1*N2 when that is not a power of two (row_tw_index reduces modulo it)
     int stagger;     // row kernel: start delay of the second half of the grid, units of ~1024 clocks (0: none)
     // diagnostic builds (-DFNFT_AMD_STAMPS) only: per-wave s_memtime stamps of the row kernel's phases,
     // 16 slots per wave, or NULL
@@ -1425,9 +1428,10 @@ template <int N1, int R, int BC, bool DB> FA_DEV void body_col_fwd(const BigLeve
 FA_DEV unsigned row_tw_index(const BigLevel &G, int k1, int x)
 {
     if (!G.rtwist) return (unsigned)k1 * (unsigned)x;
-    const unsigned long long len4 = 4ull * (unsigned long long)G.N1 * (unsigned long long)G.N2;   // a power of two
+    const unsigned long long len4 = 4ull * (unsigned long long)G.N1 * (unsigned long long)G.N2;
     const unsigned long long c1 = 4ull * (unsigned long long)k1 + len4 - 1ull;                     // 4 k1 - 1 (mod 4N)
-    return (unsigned)((c1 * (unsigned long long)x) & (len4 - 1ull));
+    if (G.row_mod) return (unsigned)((c1 * (unsigned long long)x) % G.row_mod);                    // N1 = 3*2^j
+    return (unsigned)((c1 * (unsigned long long)x) & (len4 - 1ull));                               // a power of two
 }
 
 template <int N2, int R> struct MidIO {

@@ -139,6 +139,7 @@ public:
     // the current level arrays hold
     bool want_real = false;
     bool real_run = false;
+    bool use_r3 = true;      // column lengths 3*2^j on the split levels of the real path
     // 4SPLIT4A/B front end (set_front): Din input samples per signal, every nskip-th step kept,
     // ups preprocessed samples per kept step; D = ups * Dsub matrices enter the tree
     size_t Din = 0, nskip = 1;
@@ -153,6 +154,9 @@ public:
     cplx *tm_out = nullptr;
     cplx *twtab = nullptr;   // concatenated tables for N = 2,4,...,kMaxTwTable
     cplx *twlo = nullptr;    // exp(-2 pi i j / 2^24), j < 4096
+    // lengths 3*2^b (column transforms of the real path, nft_real.h): tables for L = 3, 6, ..., 3*2^kTw3MaxLog back to
+    // back (offset L - 3), and the fine table exp(-2 pi i j/(3*2^22)), j < 4096, of the master pair for 3*2^22
+    cplx *tw3tab = nullptr, *twlo3 = nullptr;
     size_t Lc = 0;           // chirp transform length
     size_t bytes = 0;
     int cur = 0;             // index of the body/tail/scale set holding the current level
@@ -201,6 +205,17 @@ public:
     const cplx *tw_table(size_t N) const
     {   // tables are stored back to back: N=2 at offset 0, N=4 at 2, N=8 at 6, ... offset = N-2
         return twtab + (N - 2);
+    }
+    static constexpr int kTw3MaxLog = 12;
+    const cplx *tw3_table(size_t L) const { return tw3tab + (L - 3); }
+    BigTwiddle big_tw3(size_t N) const   // N = 3*2^a <= 3*2^22
+    {
+        BigTwiddle t;
+        t.hi = tw3_table((size_t)3 << 10);   // exp(-2 pi i jh/3072)
+        t.lo = twlo3;
+        t.fine_log2 = kFineLog2;
+        t.shift = 22 - nft_log2(N / 3);
+        return t;
     }
     BigTwiddle big_tw(size_t N) const
     {
@@ -254,6 +269,7 @@ public:
         }
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
         ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
+        if (kdv) ok = ok && alloc(tw3tab, (size_t)3 << (kTw3MaxLog + 1)) && alloc(twlo3, (size_t)1 << kFineLog2);
         if (kdv) {
             ok = ok && alloc(rneg, batch * D);
             if (ok) {
@@ -294,7 +310,7 @@ public:
         be.free(max2[0]); be.free(max2[1]); be.free(status); be.free(Y); be.free(Z); be.free(Z2);
         be.free(chY); be.free(chV); be.free(chH); be.free(chVS); be.free(tm_out); be.free(twtab); be.free(twlo);
         be.free(prog_bfrac); be.free(prog_mw); be.free(prog_ptr); be.free(prog_fac);
-        be.free(rneg); be.free(dbg_stamps); be.free(wuser);
+        be.free(rneg); be.free(dbg_stamps); be.free(wuser); be.free(tw3tab); be.free(twlo3);
         be.free(qpre); be.free(rsX); be.free(rsX12); be.free(rsQ12); be.free(rsY); be.free(rsV);
     }
 
@@ -315,6 +331,23 @@ public:
             lo[j] = cmake((double)cosl(a), (double)sinl(a));
         }
         be.h2d(twlo, lo.data(), lo.size() * sizeof(cplx));
+        if (tw3tab) {
+            std::vector<cplx> h3((size_t)3 << (kTw3MaxLog + 1));
+            for (int b = 0; b <= kTw3MaxLog; b++) {
+                const size_t Lb = (size_t)3 << b;
+                for (size_t j = 0; j < Lb; j++) {
+                    const long double a = -tau * (long double)j / (long double)Lb;
+                    h3[Lb - 3 + j] = cmake((double)cosl(a), (double)sinl(a));
+                }
+            }
+            be.h2d(tw3tab, h3.data(), h3.size() * sizeof(cplx));
+            const long double nmax3 = 3.0L * (long double)((size_t)1 << 22);
+            for (size_t j = 0; j < lo.size(); j++) {
+                const long double a = -tau * (long double)j / nmax3;
+                lo[j] = cmake((double)cosl(a), (double)sinl(a));
+            }
+            be.h2d(twlo3, lo.data(), lo.size() * sizeof(cplx));
+        }
     }
 
     // ---- front end: fnft__nse_discretization_preprocess_signal (:386-656) + level 0 ------------
@@ -476,6 +509,15 @@ public:
         size_t n = start_n, d = start_d;
         bool y_from_bridge = false, in_pending = false;
         int zcur = 0, mcur = 0;
+        // degrees 3*2^a: the split levels take columns of 3*K rows of kRowGen points -- transform length M = d exactly
+        // (nft_real.h) -- when the last level's column length is instantiated
+        bool r3 = false;
+        if (use_r3 && tw3tab) {
+            size_t odd = start_d;
+            while (odd % 2 == 0) odd /= 2;
+            const size_t dtop = start_d * (start_n / batch) / 2;   // degree of the last level's factors
+            r3 = (odd == 3) && dtop % (size_t)kRowGen == 0 && dtop / (size_t)kRowGen <= (size_t)3 * kR3MaxK;
+        }
         while (n / batch > 1) {
             TreeLevel L;
             L.body_in = body[cur]; L.tail_in = tail[cur]; L.scale_in = scale[cur];
@@ -496,6 +538,37 @@ public:
             bool ok;
             if (d <= (size_t)kSchoolMaxDeg) {
                 ok = dispatch_rpair_school(be, L);
+            } else if (r3 && d % (size_t)kRowGen == 0 && d / (size_t)kRowGen >= 3) {
+                BigLevel G;
+                std::memset(&G, 0, sizeof(G));
+                G.L = L;
+                G.Y = Y;
+                G.Z = zcur ? Z2 : Z;
+                G.N2 = kRowGen;
+                G.N1 = (int)(d / (size_t)kRowGen);   // 3*K
+                const size_t K = (size_t)G.N1 / 3;
+                G.btw = big_tw3(4 * d);              // row twiddle w_{4M}^{(4 k1 - 1) n2}, M = d
+                G.rtwist = 1;
+                G.row_mod = 4ull * (unsigned long long)d;
+                G.tw1 = tw_table(K >= 2 ? K : 2);
+                G.tw2 = tw_table((size_t)G.N2);
+                G.tw1x2 = tw_table(2 * K);
+                G.tw3 = tw3_table((size_t)G.N1);
+                G.tw3x2 = tw3_table((size_t)2 * G.N1);
+                G.twq = tw3_table((size_t)4 * G.N1);
+                G.twq2 = ((size_t)8 * G.N1 <= ((size_t)3 << kTw3MaxLog)) ? tw3_table((size_t)8 * G.N1) : nullptr;
+                G.y_unscaled = y_from_bridge ? 1 : 0;
+                ok = true;
+                if (!y_from_bridge) ok = dispatch_r3col_fwd(be, G);
+                if (ok) run_mid(be, G);
+                const bool next_split = use_bridge && (n / 2 / batch > 1) && K <= (size_t)kR3BridgeMaxK;
+                if (ok) ok = next_split ? dispatch_r3bridge(be, G) : dispatch_r3col_inv(be, G);
+                zcur ^= 1;
+                y_from_bridge = ok && next_split;
+                const bool last_level = (n / 2 / batch <= 1);
+                if (ok && last_level) be.template run<KFinalizeScales>((int)(n / 2), 1, L);
+                in_pending = !last_level;
+                mcur ^= 1;
             } else if (M <= (size_t)kRealFusedMaxM) {
                 L.tw = tw_table(M);
                 L.twx = tw_table(4 * M);

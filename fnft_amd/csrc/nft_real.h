@@ -710,3 +710,193 @@ template <int N2, int R> FA_DEV void body_mid_gen(const BigLevel &G)
         dZ[3 * zstr + o] = c1[i] * w;     // C11
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Split levels with a column length N1 = 3*K, K a power of two.  The degrees of fnft_kdvv's default scheme are
+// d = 12*2^l = 3*2^(l+2): with power-of-two transforms the folded length is the power of two ABOVE d (a third of every
+// transform is padding); with N1 = 3*K columns of N2 = 1024-point rows the length is M = d exactly.  Only the column
+// kernels see the factor 3 (decimation in time: three transforms of length K on the elements n1 = 3 m + r, then one
+// radix-3 butterfly per bin with the twiddles w_N1^(r kappa)); the row kernel is unchanged.
+//   lane (v, c): elements n1 = 3 (v + (K/R) i) + r in x[r][i]; bins k1 = (v + (K/R) i) + K t in x[t][i].
+// ---------------------------------------------------------------------------------------------
+template <int SIGN> FA_DEV void dft3(cplx &t0, cplx &t1, cplx &t2)
+{
+    const double h = 0.86602540378443864676;   // sqrt(3)/2
+    const cplx s = t1 + t2, dl = t1 - t2;
+    const cplx m = cmake(fma(-0.5, s.x, t0.x), fma(-0.5, s.y, t0.y));
+    const cplx q = cmake(-dl.y * (h * (double)SIGN), dl.x * (h * (double)SIGN));   // SIGN * i * h * (t1 - t2)
+    t0 = t0 + s;
+    t1 = m + q;
+    t2 = m - q;
+}
+// tw: table of exp(-2 pi i j/K); tw3: table of exp(-2 pi i j/(3K))
+template <int K, int R, int BC> FA_DEV void fft3_fwd(cplx (&x)[3][R], cplx *lds, int v, int c, const cplx *tw, const cplx *tw3, int &parity)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++) fft_wg<K, R, BC, -1, false, true>(x[r], lds, v, c, tw, parity);
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int kap = v + (K / R) * i;
+        cplx t1 = x[1][i] * tw3[kap], t2 = x[2][i] * tw3[2 * kap];
+        dft3<-1>(x[0][i], t1, t2);
+        x[1][i] = t1;
+        x[2][i] = t2;
+    }
+}
+template <int K, int R, int BC> FA_DEV void fft3_inv(cplx (&x)[3][R], cplx *lds, int v, int c, const cplx *tw, const cplx *tw3, int &parity)
+{
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int kap = v + (K / R) * i;
+        dft3<+1>(x[0][i], x[1][i], x[2][i]);
+        x[1][i] = x[1][i] * cconj(tw3[kap]);
+        x[2][i] = x[2][i] * cconj(tw3[2 * kap]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) fft_wg<K, R, BC, +1, false, true>(x[r], lds, v, c, tw, parity);
+}
+
+// real coefficients -> column transform (first split level); M = N1*N2 = d exactly
+//   grid.x = N2/BC tiles, grid.y = 4*n_in polynomials
+template <int K, int R, int BC> FA_DEV void body_r3col_fwd(const BigLevel &G)
+{
+    constexpr int N1 = 3 * K;
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int poly = FA_BID_Y;
+    const int e = poly / L.n_in, mat = poly % L.n_in;
+    const int d = L.d, N2 = G.N2;
+    const double sc = level_in_scale(L, mat);
+    const double *src = (const double *)L.body_in + (size_t)e * L.plane + (size_t)mat * d;
+    const double tl = ((const double *)L.tail_in)[(size_t)e * L.n_in + mat] * sc;
+    cplx x[3][R];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int n1 = 3 * (v + (K / R) * i) + r;
+            const long long idx = (long long)n1 * N2 + n2;
+            const double re = src[idx] * sc;
+            const double im = (idx == 0) ? tl : 0.0;   // the constant term, index d = M, folds onto 0
+            const cplx w = G.twq[n1];
+            x[r][i] = cmake(fma(re, w.x, im * w.y), fma(im, w.x, -(re * w.y)));
+        }
+    int parity = 0;
+    fft3_fwd<K, R, BC>(x, lds, v, c, G.tw1, G.tw3, parity);
+    cplx *dst = G.Y + (size_t)poly * N1 * N2;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < R; i++) dst[yz_index(N1, N2, v + (K / R) * i + K * t, n2)] = x[t][i];
+}
+
+// last split level: inverse column transform, untwist, unfold -> real coefficients
+template <int K, int R, int BC> FA_DEV void body_r3col_inv(const BigLevel &G)
+{
+    constexpr int N1 = 3 * K;
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int poly = FA_BID_Y;
+    const int n_out = L.n_in / 2;
+    const int e = poly / n_out, P = poly % n_out;
+    const int N2 = G.N2;
+    const long long M = (long long)N1 * N2;
+    const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);   // wave-uniform
+    cplx x[3][R];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < R; i++) x[t][i] = src[yz_index(N1, N2, v + (K / R) * i + K * t, n2)];
+    int parity = 0;
+    fft3_inv<K, R, BC>(x, lds, v, c, G.tw1, G.tw3, parity);
+    double *dst = (double *)L.body_out + (size_t)e * L.plane + (size_t)P * (2 * M);
+    const double inv = 1.0 / (double)N1;
+    double m2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int n1 = 3 * (v + (K / R) * i) + r;
+            const long long idx = (long long)n1 * N2 + n2;
+            const cplx val = (x[r][i] * inv) * G.twq[n1];
+            double re = val.x;
+            if (idx == 0) {
+                const double tp = rsplit_tail_product(L, P, e, sA, sB);
+                re += tp;   // coefficient 2d = 2M came back on 0 with a minus sign
+                ((double *)L.tail_out)[(size_t)e * n_out + P] = tp;
+                m2 = fmax(m2, tp * tp);
+            }
+            dst[idx] = re;
+            dst[idx + M] = val.y;
+            m2 = fmax(m2, fmax(re * re, val.y * val.y));
+        }
+    fa_wave_atomic_max_hi32(&L.max2_out[(size_t)P * kMax2Slots + max2_slot()], m2);   // P is uniform in the workgroup
+}
+
+// between two split levels: inverse column transform (3K), untwist, unfold; fold, twist, forward column transform (3*2K)
+// of the next level.  The next level's sub-sequence r (elements n1' = 3 m' + r, m' < 2K) is [Re z_r[m] | Im z_r[m]]:
+// the same lane holds both halves.
+template <int K, int R, int BC> FA_DEV void body_r3bridge(const BigLevel &G)
+{
+    constexpr int N1 = 3 * K;
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    const TreeLevel &L = G.L;
+    const int tid = FA_TID;
+    const int c = tid % BC, v = tid / BC;
+    const int n2 = FA_BID * BC + c;
+    const int poly = FA_BID_Y;
+    const int n_out = L.n_in / 2;
+    const int e = poly / n_out, P = poly % n_out;
+    const int N2 = G.N2;
+    const cplx *src = G.Z + (size_t)poly * N1 * N2;
+    const double sA = level_in_scale(L, 2 * P), sB = level_in_scale(L, 2 * P + 1);   // wave-uniform
+    cplx x[3][R];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < R; i++) x[t][i] = src[yz_index(N1, N2, v + (K / R) * i + K * t, n2)];
+    int parity = 0;
+    fft3_inv<K, R, BC>(x, lds, v, c, G.tw1, G.tw3, parity);
+    const double inv = 1.0 / (double)N1;
+    double m2 = 0.0;
+    cplx y[3][2 * R];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int n1 = 3 * (v + (K / R) * i) + r;
+            const long long idx = (long long)n1 * N2 + n2;
+            const cplx val = (x[r][i] * inv) * G.twq[n1];
+            double re = val.x;
+            const double im = val.y;   // coefficients idx and idx + M of the product
+            double im0 = 0.0;
+            if (idx == 0) {
+                const double tp = rsplit_tail_product(L, P, e, sA, sB);
+                re += tp;
+                im0 = tp;   // the next level's constant term folds onto its element 0
+                ((double *)L.tail_out)[(size_t)e * n_out + P] = tp;
+                m2 = fmax(m2, tp * tp);
+            }
+            m2 = fmax(m2, fmax(re * re, im * im));
+            const cplx w0 = G.twq2[n1], w1 = G.twq2[n1 + N1];   // exp(-2 pi i n1'/(8 N1)); the twist is the conjugate
+            y[r][i] = cmake(fma(re, w0.x, im0 * w0.y), fma(im0, w0.x, -(re * w0.y)));
+            y[r][R + i] = cmake(im * w1.x, -(im * w1.y));
+        }
+    fa_wave_atomic_max_hi32(&L.max2_out[(size_t)P * kMax2Slots + max2_slot()], m2);   // P is uniform in the workgroup
+    fft3_fwd<2 * K, 2 * R, BC>(y, lds, v, c, G.tw1x2, G.tw3x2, parity);
+    cplx *dst = G.Y + (size_t)poly * (2 * N1) * N2;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < 2 * R; i++) dst[yz_index(2 * N1, N2, v + (K / R) * i + 2 * K * t, n2)] = y[t][i];
+}
