@@ -102,6 +102,7 @@ EXPORTED = [
     "fnft__nse_scatter_matrix", "fnft__poly_roots_fftgridsearch", "fnft__poly_roots_fftgridsearch_paraherm",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device", "fnft_amd_kdvv_plan_set_real_mode",
+    "fnft_amd_release_cached",
 ]
 
 _lib = None
@@ -163,6 +164,8 @@ def load(path=None):
     L.fnft__kdv_fscatter.argtypes = [sz, vp, dbl, vp, C.POINTER(sz), C.POINTER(i32), C.c_int]
     L.fnft_amd_kdvv_plan_create.restype = i32
     L.fnft_amd_kdvv_plan_create.argtypes = [C.POINTER(vp), sz, sz, sz, C.c_int, C.c_int]
+    L.fnft_amd_release_cached.restype = None
+    L.fnft_amd_release_cached.argtypes = [C.c_int]
     L.fnft_amd_kdvv_plan_set_real_mode.restype = i32
     L.fnft_amd_kdvv_plan_set_real_mode.argtypes = [vp, C.c_int]
     L.fnft_amd_kdvv_contspec_device.restype = i32
@@ -270,7 +273,7 @@ def default_opts():
 # --------------------------------------------------------------------------------------------
 def fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="REFLECTION_COEFFICIENT",
               normalization_flag=1, opts=None, want_contspec=True, bound_states=None, K=None,
-              richardson=False, normconsts=None):
+              richardson=False, normconsts=None, out=None):
     """fnft_nsev() through the C ABI with host (numpy) buffers.  Returns (rc, contspec).
     bound_states / normconsts: caller-allocated complex128 arrays (K = capacity of bound_states);
     see fnft_nsev_ds() for the discrete spectrum with managed buffers."""
@@ -285,7 +288,11 @@ def fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT4B", contspec_type="RE
     Tn = None if T is None else np.ascontiguousarray(T, np.float64)
     XIn = None if XI is None else np.ascontiguousarray(XI, np.float64)
     fac = CS_FACTOR.get(int(opts.contspec_type), 3)
-    cs = np.zeros(max(M * fac, 1), np.complex128) if want_contspec else None
+    # out: a caller-owned result array that is reused between calls (what a C caller has: the reference's caller
+    # allocates contspec once); without it a fresh zeroed array is made per call (its pages are first touched by the copy)
+    if out is not None:
+        assert out.dtype == np.complex128 and out.flags.c_contiguous and out.size >= max(M * fac, 1)
+    cs = (out if out is not None else np.zeros(max(M * fac, 1), np.complex128)) if want_contspec else None
     Kc = C.c_size_t(K if K is not None else 0)
     rc = L.fnft_nsev(q.size, _ptr(q), None if Tn is None else _ptr(Tn), M,
                      None if cs is None else _ptr(cs), None if XIn is None else _ptr(XIn),
@@ -303,7 +310,7 @@ DSTYPE = {"NORMING_CONSTANTS": 0, "RESIDUES": 1, "BOTH": 2}
 
 
 def fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="SUBSAMPLE_AND_REFINE", bsfilt="FULL", niter=10,
-                 Dsub=0, dstype="BOTH", guesses=None, richardson=False, M=0, XI=None, K=None):
+                 Dsub=0, dstype="BOTH", guesses=None, richardson=False, M=0, XI=None, K=None, bufs=None):
     """Discrete spectrum (kappa = +1) through the drop-in fnft_nsev().
     Returns (rc, bound_states, normconsts, residues[, contspec if M > 0])."""
     L = load()
@@ -318,13 +325,14 @@ def fnft_nsev_ds(q, T, discretization="2SPLIT4B", bsloc="SUBSAMPLE_AND_REFINE", 
     opts.contspec_type = CSTYPE["BOTH"]
     opts.richardson_extrapolation_flag = 1 if richardson else 0
     cap = int(K) if K is not None else int(L.fnft_nsev_max_K(q.size, C.byref(opts)))
-    bs = np.zeros(max(cap, 1), np.complex128)
+    # bufs: caller-owned arrays {"bs", "nc", "cs"} reused between calls (what a C caller of the reference has)
+    bs = bufs["bs"] if bufs else np.zeros(max(cap, 1), np.complex128)
     if guesses is not None:
         g = _c128(guesses)
         bs[: g.size] = g
         cap = g.size
-    nc = np.zeros(2 * max(cap, 1), np.complex128)
-    cs = np.zeros(3 * M, np.complex128) if M > 0 else None
+    nc = bufs["nc"] if bufs else np.zeros(2 * max(cap, 1), np.complex128)
+    cs = (bufs["cs"] if bufs else np.zeros(3 * M, np.complex128)) if M > 0 else None
     Tn = np.ascontiguousarray(T, np.float64)
     XIn = None if XI is None else np.ascontiguousarray(XI, np.float64)
     Kc = C.c_size_t(cap)
@@ -737,3 +745,8 @@ class Plan:
         rc = self.L.fnft_amd_plan_get_transfer_matrix(self.h, b, _ptr(buf), C.byref(deg), C.byref(W))
         d = deg.value
         return int(rc), d, buf[: 4 * (d + 1)].reshape(4, d + 1).copy(), int(W.value)
+
+
+def release_cached(device=-1):
+    """fnft_amd_release_cached: give the host-pointer entry points' cached plans / work arrays back to the driver."""
+    load().fnft_amd_release_cached(int(device))

@@ -15,11 +15,93 @@ extern "C" void fnft_amd__warn(const char *msg, const char *func, int line);   /
 static const char *const kNotBandlimitedMsg =
     "Signal does not appear to be bandlimited. Interpolation step may be inaccurate. Try to reduce the step size, "
     "or switch to a discretization that does not require interpolation";
-// Host-pointer entry points share cached plans and workspaces: one call at a time (SURVEY 8b allows an
-// internal mutex); device-resident plans are independent objects with their own lock.
-static std::mutex g_host_call_mtx;
+// Host-pointer entry points share cached plans and workspaces PER DEVICE: one call at a time on a device (SURVEY 8b
+// allows an internal mutex), calls on different devices run concurrently; device-resident plans are independent
+// objects with their own lock.
+static std::mutex &host_call_mutex_of(int d)
+{
+    static std::mutex m[64];
+    return m[(unsigned)d % 64u];
+}
+static std::mutex &host_call_mutex()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return host_call_mutex_of(d);
+}
 
 using Plan = NftPlan<HipBackend>;
+
+// ---- cache of released device blocks (HipBackend::alloc / free) ------------------------------------------------------
+// Sizes are rounded up to a bucket (powers of two below 1 MiB, four steps per octave above: at most 25 % slack) so
+// that the work arrays of a repeated call find the blocks of the previous one.  At most kPoolMaxCached bytes per
+// process stay cached; fnft_amd_release_cached() returns everything to the driver.
+namespace {
+struct DevPool {
+    std::mutex m;
+    std::multimap<std::pair<int, size_t>, void *> idle;    // (device, bucket) -> block
+    std::map<void *, std::pair<int, size_t>> live;         // block -> (device, bucket)
+    size_t cached = 0;
+    static constexpr size_t kPoolMaxCached = (size_t)6 << 30;
+    static size_t bucket(size_t b)
+    {
+        if (b < 256) b = 256;
+        size_t p = 256;
+        while (p < b) p *= 2;
+        if (p <= ((size_t)1 << 20)) return p;
+        const size_t step = p / 8;          // p/2 < b <= p: buckets p/2 + k*p/8
+        return (b + step - 1) / step * step;
+    }
+    void trim_locked(int device)
+    {
+        for (auto it = idle.begin(); it != idle.end();) {
+            if (device < 0 || it->first.first == device) {
+                cached -= it->first.second;
+                (void)hipFree(it->second);
+                it = idle.erase(it);
+            } else ++it;
+        }
+    }
+};
+DevPool &pool() { static DevPool *p = new DevPool(); return *p; }   // never destroyed: blocks outlive static teardown
+}  // namespace
+
+void *fa_pool_alloc(size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { g_last_error = "hipGetDevice failed"; return nullptr; }
+    DevPool &P = pool();
+    const size_t bk = DevPool::bucket(bytes);
+    std::lock_guard<std::mutex> lk(P.m);
+    auto it = P.idle.find(std::make_pair(dev, bk));
+    void *p = nullptr;
+    if (it != P.idle.end()) {
+        p = it->second;
+        P.idle.erase(it);
+        P.cached -= bk;
+    } else {
+        if (hipMalloc(&p, bk) != hipSuccess) {
+            (void)hipGetLastError();
+            P.trim_locked(dev);   // out of memory: give the cached blocks back and try once more
+            if (!hip_ok(hipMalloc(&p, bk), "hipMalloc")) return nullptr;
+        }
+    }
+    P.live[p] = std::make_pair(dev, bk);
+    return p;
+}
+
+void fa_pool_free(void *p)
+{
+    DevPool &P = pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) { (void)hipFree(p); return; }
+    const std::pair<int, size_t> key = it->second;
+    P.live.erase(it);
+    if (P.cached + key.second > DevPool::kPoolMaxCached) { (void)hipFree(p); return; }
+    P.idle.insert(std::make_pair(key, p));
+    P.cached += key.second;
+}
 
 struct fnft_amd_plan {
     HipBackend be;
@@ -74,6 +156,18 @@ struct DeviceGuard {
         }
     }
 };
+
+// state the host-pointer entry points keep between calls, per device (fnft_amd_release_cached gives it back)
+struct Peeler {
+    HipBackend be;
+    NftLayerPeelingDev<HipBackend> lp;
+    Peeler() : lp(be, 1.0, 1, 1) {}
+};
+static std::map<int, Peeler *> g_peelers;
+static std::mutex g_peelers_mtx;   // the map itself; a device's peeler is used under that device's host-call lock
+static std::mutex g_cache_mtx;     // the two plan caches below
+static std::map<std::tuple<int, size_t, size_t, int, size_t>, fnft_amd_plan *> g_nsev_cache;   // (dev, D, M, disc, nskip)
+static std::map<std::tuple<int, size_t, size_t, int>, fnft_amd_plan *> g_kdvv_cache;           // (dev, D, M, disc)
 
 extern "C" {
 
@@ -575,18 +669,17 @@ FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer
     const bool modal = discretization == fnft_nse_discretization_2SPLIT2_MODAL;
     if (!modal && discretization != fnft_nse_discretization_2SPLIT2A) return FNFT_EC_INVALID_ARGUMENT;
     if (current_device() < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     // one resident peeler per device: its pair-product plans (one per degree) and work arrays are reused by later
     // calls; sizes beyond 2^18 samples release everything again (workspace footprint)
-    struct Peeler {
-        HipBackend be;
-        NftLayerPeelingDev<HipBackend> lp;
-        Peeler() : lp(be, 1.0, 1, 1) {}
-    };
-    static std::map<int, Peeler *> peelers;
     const int dev = current_device();
-    Peeler *&pp = peelers[dev];
-    if (!pp) pp = new (std::nothrow) Peeler();
+    Peeler *pp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_peelers_mtx);
+        Peeler *&slot = g_peelers[dev];
+        if (!slot) slot = new (std::nothrow) Peeler();
+        pp = slot;
+    }
     if (!pp) return FNFT_EC_NOMEM;
     pp->be.failed = false;
     pp->lp.eps_t = eps_t;
@@ -607,7 +700,7 @@ FNFT_INT fnft__poly_specfact(const FNFT_UINT deg, FNFT_COMPLEX const *const poly
     if (deg == 0 || !poly || !result || oversampling_factor == 0) return FNFT_EC_INVALID_ARGUMENT;   // :31-38
     if (kappa != 0 && kappa != 1 && kappa != -1) return FNFT_EC_INVALID_ARGUMENT;                     // :105-107
     if (current_device() < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     NftInverseDev<HipBackend> inv(be);
     int warn = 0;
@@ -624,7 +717,7 @@ extern "C" FNFT_INT fnft_amd__inverse_transfer_matrix(FNFT_UINT M, FNFT_COMPLEX 
                                                       FNFT_REAL phase_factor, int *warn_specfact, int *warn_maxiter)
 {
     if (current_device() < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     NftInverseDev<HipBackend> inv(be);
     const int rc = inv.transfer_matrix(M, contspec, XI, K, bound_states, D, T, deg, tm, (int)kappa, cstype, method,
@@ -648,7 +741,7 @@ extern "C" FNFT_INT fnft_amd__inverse_add_discrete(FNFT_UINT K, const FNFT_COMPL
             if (bs[i].imag() < bs[j].imag()) { std::swap(bs[i], bs[j]); std::swap(nc[i], nc[j]); }
     for (size_t i = 0; i + 1 < K; i++)
         if (bs[i + 1] == bs[i]) return FNFT_EC_SANITY_CHECK_FAILED;   // :756-761
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     int rc = FNFT_SUCCESS;
     if (residues) {                                                    // :771-795
@@ -704,7 +797,7 @@ FNFT_INT fnft__misc_resample(const FNFT_UINT D, const FNFT_REAL eps_t, FNFT_COMP
     if (D <= 2 || !q || !q_new || eps_t == 0.0) return FNFT_EC_INVALID_ARGUMENT;
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     int warn = 0;
     const int rc = Plan::resample_host(be, D, eps_t, q, delta, q_new, &warn);
@@ -720,7 +813,7 @@ FNFT_INT fnft__poly_roots_fasteigen(const FNFT_UINT deg, FNFT_COMPLEX const *con
     if (deg == 0) return FNFT_SUCCESS;
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     NftDiscSpec<HipBackend> ds(be);
     cplx *d_coef = (cplx *)be.alloc((deg + 1) * sizeof(cplx));
@@ -752,7 +845,7 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
     if (D < 2 || !(T[0] < T[1])) return FNFT_EC_INVALID_ARGUMENT;
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     NftDiscSpec<HipBackend> ds(be);
     NftDiscSpec<HipBackend>::Prepared P;
@@ -826,7 +919,7 @@ FNFT_INT fnft__poly_roots_fftgridsearch(const FNFT_UINT deg, FNFT_COMPLEX const 
     if (!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY) return FNFT_EC_INVALID_ARGUMENT;
     if (!roots) return FNFT_EC_INVALID_ARGUMENT;
     if (current_device() < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     size_t M = *M_ptr;
     const int rc = gridsearch_common(deg, p, &M, PHI, roots, false);
     if (rc == FNFT_SUCCESS) *M_ptr = M;
@@ -840,7 +933,7 @@ FNFT_INT fnft__poly_roots_fftgridsearch_paraherm(const FNFT_UINT deg, FNFT_COMPL
     if (!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY) return FNFT_EC_INVALID_ARGUMENT;
     if (!roots) return FNFT_EC_INVALID_ARGUMENT;
     if (current_device() < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     size_t M = *M_ptr;
     const int rc = gridsearch_common(deg, p, &M, PHI, roots, true);
     if (rc == FNFT_SUCCESS) *M_ptr = M;
@@ -860,7 +953,7 @@ FNFT_INT fnft__nse_scatter_matrix(const FNFT_UINT D, FNFT_COMPLEX const *const q
         return FNFT_EC_INVALID_ARGUMENT;
     if (discretization != fnft_nse_discretization_BO) return FNFT_EC_NOT_YET_IMPLEMENTED;
     if (current_device() < 0) return FNFT_EC_OTHER;
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     BsParams B;
     std::memset(&B, 0, sizeof(B));
@@ -962,14 +1055,13 @@ FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, cons
 FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const FNFT_REAL *T, FNFT_UINT M,
                                       FNFT_COMPLEX *contspec, const FNFT_REAL *XI, int discretization)
 {
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
-    static std::mutex cache_mtx;
-    static std::map<std::tuple<int, size_t, size_t, int>, fnft_amd_plan *> cache;
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
     fnft_amd_plan *P = nullptr;
     {
-        std::lock_guard<std::mutex> lk(cache_mtx);
+        std::lock_guard<std::mutex> lk(g_cache_mtx);
+        auto &cache = g_kdvv_cache;
         auto key = std::make_tuple(dev, (size_t)D, (size_t)M, discretization);
         auto it = cache.find(key);
         if (it == cache.end()) {
@@ -984,10 +1076,11 @@ FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const 
             P = it->second;
         }
     }
-    cplx *du = nullptr, *dcs = nullptr;
-    if (!hip_ok(hipMalloc((void **)&du, D * sizeof(cplx)), "hipMalloc")) return FNFT_EC_NOMEM;
-    if (!hip_ok(hipMalloc((void **)&dcs, M * sizeof(cplx)), "hipMalloc")) {
-        (void)hipFree(du);
+    // staging buffers on the device: from the block cache (no hipMalloc / hipFree per call)
+    cplx *du = (cplx *)fa_pool_alloc(D * sizeof(cplx)), *dcs = (cplx *)fa_pool_alloc(M * sizeof(cplx));
+    if (!du || !dcs) {
+        if (du) fa_pool_free(du);
+        if (dcs) fa_pool_free(dcs);
         return FNFT_EC_NOMEM;
     }
     {   // the potential is in host memory: look at it here instead of asking the device
@@ -1003,8 +1096,8 @@ FNFT_INT fnft_amd__kdvv_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *u, const 
     if (rc == FNFT_SUCCESS)
         if (!hip_ok(hipMemcpy(contspec, dcs, M * sizeof(cplx), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
             rc = FNFT_EC_OTHER;
-    (void)hipFree(du);
-    (void)hipFree(dcs);
+    fa_pool_free(du);
+    fa_pool_free(dcs);
     return rc;
 }
 
@@ -1015,7 +1108,7 @@ FNFT_INT fnft_amd__nsev_discspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                                       int richardson, FNFT_UINT *K_ptr, FNFT_COMPLEX *bound_states,
                                       FNFT_COMPLEX *normconsts_or_residues, int *warn)
 {
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
@@ -1041,14 +1134,13 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
                                       FNFT_INT kappa, int discretization, int contspec_type,
                                       FNFT_INT normalization_flag, FNFT_UINT nskip)
 {
-    std::lock_guard<std::mutex> host_lk(g_host_call_mtx);
-    static std::mutex cache_mtx;
-    static std::map<std::tuple<int, size_t, size_t, int, size_t>, fnft_amd_plan *> cache;
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
     fnft_amd_plan *P = nullptr;
     {
-        std::lock_guard<std::mutex> lk(cache_mtx);
+        std::lock_guard<std::mutex> lk(g_cache_mtx);
+        auto &cache = g_nsev_cache;
         auto key = std::make_tuple(dev, (size_t)D, (size_t)M, discretization, (size_t)nskip);
         auto it = cache.find(key);
         if (it == cache.end()) {
@@ -1065,10 +1157,13 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
         }
     }
     const size_t cs_len = M * (contspec_type == 0 ? 1 : (contspec_type == 1 ? 2 : 3));
-    cplx *dq = nullptr, *dcs = nullptr;
-    if (!hip_ok(hipMalloc((void **)&dq, D * sizeof(cplx)), "hipMalloc")) return FNFT_EC_NOMEM;
-    if (!hip_ok(hipMalloc((void **)&dcs, (cs_len ? cs_len : 1) * sizeof(cplx)), "hipMalloc")) {
-        (void)hipFree(dq);
+    // staging buffers on the device: from the block cache (no hipMalloc / hipFree per call).  The caller's arrays are
+    // ordinary pageable memory: hipMemcpy moves them at the link rate once their pages are resident.
+    cplx *dq = (cplx *)fa_pool_alloc(D * sizeof(cplx));
+    cplx *dcs = (cplx *)fa_pool_alloc((cs_len ? cs_len : 1) * sizeof(cplx));
+    if (!dq || !dcs) {
+        if (dq) fa_pool_free(dq);
+        if (dcs) fa_pool_free(dcs);
         return FNFT_EC_NOMEM;
     }
     FNFT_INT rc = FNFT_SUCCESS;
@@ -1084,9 +1179,49 @@ FNFT_INT fnft_amd__nsev_contspec_host(FNFT_UINT D, const FNFT_COMPLEX *q, const 
     if (rc == FNFT_SUCCESS && contspec && cs_len)
         if (!hip_ok(hipMemcpy(contspec, dcs, cs_len * sizeof(cplx), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
             rc = FNFT_EC_OTHER;
-    (void)hipFree(dq);
-    (void)hipFree(dcs);
+    fa_pool_free(dq);
+    fa_pool_free(dcs);
     return rc;
+}
+
+// Everything the host-pointer entry points keep on `device` between calls goes back to the driver: cached plans, the
+// resident layer-peeling state of fnft__nse_finvscatter / fnft_nsev_inverse, and the cache of released device blocks.
+// device < 0: every device.  Device-resident plans the caller created are not touched.
+void fnft_amd_release_cached(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return;
+    for (int d = 0; d < ndev; d++) {
+        if (device >= 0 && d != device) continue;
+        std::lock_guard<std::mutex> host_lk(host_call_mutex_of(d));
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mtx);
+            for (auto it = g_nsev_cache.begin(); it != g_nsev_cache.end();) {
+                if (std::get<0>(it->first) == d) { fnft_amd_plan_destroy(it->second); it = g_nsev_cache.erase(it); }
+                else ++it;
+            }
+            for (auto it = g_kdvv_cache.begin(); it != g_kdvv_cache.end();) {
+                if (std::get<0>(it->first) == d) { fnft_amd_plan_destroy(it->second); it = g_kdvv_cache.erase(it); }
+                else ++it;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_peelers_mtx);
+            auto it = g_peelers.find(d);
+            if (it != g_peelers.end() && it->second) {
+                DeviceGuard dg(d);
+                if (dg.ok) {
+                    (void)hipDeviceSynchronize();
+                    it->second->lp.destroy();
+                }
+            }
+        }
+        DeviceGuard dg(d);
+        if (dg.ok) (void)hipDeviceSynchronize();
+        DevPool &P = pool();
+        std::lock_guard<std::mutex> lk(P.m);
+        P.trim_locked(d);
+    }
 }
 
 }  // extern "C"

@@ -24,6 +24,9 @@ inline bool hip_ok(hipError_t e, const char *what)
     return false;
 }
 
+void *fa_pool_alloc(size_t bytes);   // hip_backend.hip
+void fa_pool_free(void *p);
+
 template <class K, class = void> struct min_waves_of { static constexpr int value = 1; };
 template <class K> struct min_waves_of<K, std::void_t<decltype(K::MIN_WAVES)>> {
     static constexpr int value = K::MIN_WAVES;
@@ -53,13 +56,16 @@ struct HipBackend {
     size_t launches_used = 0;
     bool launch_timing = false;
 
+    // device memory comes from a per-device cache of released blocks (hip_backend.hip: fa_pool_*): the host-pointer
+    // entry points allocate their work arrays per call, and hipMalloc / hipFree cost 0.1-1 ms each (hipFree also
+    // waits for the device).  Blocks are reused in stream order on the null stream the host-pointer calls run on.
     void *alloc(size_t b)
     {
-        void *p = nullptr;
-        if (!hip_ok(hipMalloc(&p, b), "hipMalloc")) { failed = true; return nullptr; }
+        void *p = fa_pool_alloc(b);
+        if (!p) { failed = true; return nullptr; }
         return p;
     }
-    void free(void *p) { if (p) (void)hipFree(p); }
+    void free(void *p) { if (p) fa_pool_free(p); }
     void h2d(void *d, const void *s, size_t b)
     {
         // pageable source: make the copy complete before the caller's buffer can go away

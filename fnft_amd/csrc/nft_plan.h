@@ -314,39 +314,53 @@ public:
         be.free(qpre); be.free(rsX); be.free(rsX12); be.free(rsQ12); be.free(rsY); be.free(rsV);
     }
 
-    void upload_twiddles()
-    {
-        std::vector<cplx> h((size_t)2 * kMaxTwTable);
-        const long double tau = 6.283185307179586476925286766559005768L;
-        for (size_t N = 2; N <= (size_t)kMaxTwTable; N *= 2)
-            for (size_t j = 0; j < N; j++) {
-                const long double a = -tau * (long double)j / (long double)N;
-                h[N - 2 + j] = cmake((double)cosl(a), (double)sinl(a));
+    // host copies of the tables, computed once per process (long-double sines: ~2 ms per plan otherwise)
+    struct HostTables {
+        std::vector<cplx> tw, lo, tw3, lo3;
+        HostTables()
+        {
+            const long double tau = 6.283185307179586476925286766559005768L;
+            tw.resize((size_t)2 * kMaxTwTable);
+            for (size_t N = 2; N <= (size_t)kMaxTwTable; N *= 2)
+                for (size_t j = 0; j < N; j++) {
+                    const long double a = -tau * (long double)j / (long double)N;
+                    tw[N - 2 + j] = cmake((double)cosl(a), (double)sinl(a));
+                }
+            lo.resize((size_t)1 << kFineLog2);
+            const long double nmax = (long double)((size_t)1 << (2 * kFineLog2));
+            for (size_t j = 0; j < lo.size(); j++) {
+                const long double a = -tau * (long double)j / nmax;
+                lo[j] = cmake((double)cosl(a), (double)sinl(a));
             }
-        be.h2d(twtab, h.data(), h.size() * sizeof(cplx));
-        std::vector<cplx> lo((size_t)1 << kFineLog2);
-        const long double nmax = (long double)((size_t)1 << (2 * kFineLog2));
-        for (size_t j = 0; j < lo.size(); j++) {
-            const long double a = -tau * (long double)j / nmax;
-            lo[j] = cmake((double)cosl(a), (double)sinl(a));
-        }
-        be.h2d(twlo, lo.data(), lo.size() * sizeof(cplx));
-        if (tw3tab) {
-            std::vector<cplx> h3((size_t)3 << (kTw3MaxLog + 1));
+            tw3.resize((size_t)3 << (kTw3MaxLog + 1));
             for (int b = 0; b <= kTw3MaxLog; b++) {
                 const size_t Lb = (size_t)3 << b;
                 for (size_t j = 0; j < Lb; j++) {
                     const long double a = -tau * (long double)j / (long double)Lb;
-                    h3[Lb - 3 + j] = cmake((double)cosl(a), (double)sinl(a));
+                    tw3[Lb - 3 + j] = cmake((double)cosl(a), (double)sinl(a));
                 }
             }
-            be.h2d(tw3tab, h3.data(), h3.size() * sizeof(cplx));
+            lo3.resize((size_t)1 << kFineLog2);
             const long double nmax3 = 3.0L * (long double)((size_t)1 << 22);
-            for (size_t j = 0; j < lo.size(); j++) {
+            for (size_t j = 0; j < lo3.size(); j++) {
                 const long double a = -tau * (long double)j / nmax3;
-                lo[j] = cmake((double)cosl(a), (double)sinl(a));
+                lo3[j] = cmake((double)cosl(a), (double)sinl(a));
             }
-            be.h2d(twlo3, lo.data(), lo.size() * sizeof(cplx));
+        }
+    };
+    static const HostTables &host_tables()
+    {
+        static const HostTables t;
+        return t;
+    }
+    void upload_twiddles()
+    {
+        const HostTables &H = host_tables();
+        be.h2d(twtab, H.tw.data(), H.tw.size() * sizeof(cplx));
+        be.h2d(twlo, H.lo.data(), H.lo.size() * sizeof(cplx));
+        if (tw3tab) {
+            be.h2d(tw3tab, H.tw3.data(), H.tw3.size() * sizeof(cplx));
+            be.h2d(twlo3, H.lo3.data(), H.lo3.size() * sizeof(cplx));
         }
     }
 

@@ -360,6 +360,12 @@ int fnft_amd_device_count(void);
 int fnft_amd_current_device(void);
 /* Last HIP error text of the calling thread ("" if none). */
 const char *fnft_amd_last_error(void);
+/* What the host-pointer entry points keep in HBM between calls -- per device: up to four cached plans per drop-in
+ * (fnft_nsev, fnft_kdvv), the resident layer-peeling state of fnft__nse_finvscatter / fnft_nsev_inverse (plans per
+ * degree and work arrays, about 100 MB after one D = 2^18 call), and a cache of released work arrays (at most 6 GiB per
+ * process; a repeated call then performs no hipMalloc / hipFree) -- is given back to the driver.  device < 0: all
+ * devices.  Plans the caller created with fnft_amd_plan_create are not touched. */
+void fnft_amd_release_cached(int device);
 
 /* Plan for `batch` independent signals of D samples each, M spectral points, one
  * discretization.  Allocates every workspace the call needs in HBM once. */
