@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfnft_amd.so")
 ARCH = "gfx950"
 
-C_SOURCES = ["fnft_nsev_host.c", "fnft_kdvv_host.c", "fnft_nsev_inverse_host.c"]
+C_SOURCES = ["fnft_nsev_host.c", "fnft_kdvv_host.c", "fnft_nsev_inverse_host.c", "fnft_nsep_host.c"]
 
 
 def hip_sources():

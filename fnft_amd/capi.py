@@ -102,7 +102,7 @@ EXPORTED = [
     "fnft__nse_scatter_matrix", "fnft__poly_roots_fftgridsearch", "fnft__poly_roots_fftgridsearch_paraherm",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device", "fnft_amd_kdvv_plan_set_real_mode",
-    "fnft_amd_release_cached",
+    "fnft_amd_release_cached", "fnft_nsep", "fnft_nsep_default_opts",
 ]
 
 _lib = None
@@ -750,3 +750,72 @@ class Plan:
 def release_cached(device=-1):
     """fnft_amd_release_cached: give the host-pointer entry points' cached plans / work arrays back to the driver."""
     load().fnft_amd_release_cached(int(device))
+
+
+# --------------------------------------------------------------------------------------------
+# fnft_nsep (include/fnft_amd.h section 5)
+# --------------------------------------------------------------------------------------------
+NSEP_LOC = {"SUBSAMPLE_AND_REFINE": 0, "GRIDSEARCH": 1, "MIXED": 2}
+NSEP_FILT = {"NONE": 0, "MANUAL": 1, "AUTO": 2}
+
+
+class NsepOpts(C.Structure):
+    """fnft_nsep_opts_t, include/fnft_nsep.h:140-151 (same field order)."""
+    _fields_ = [("localization", C.c_int), ("filtering", C.c_int), ("bounding_box", C.c_double * 4),
+                ("max_evals", C.c_size_t), ("discretization", C.c_int), ("normalization_flag", C.c_int32),
+                ("floquet_range", C.c_double * 2), ("points_per_spine", C.c_size_t), ("Dsub", C.c_size_t),
+                ("tol", C.c_double)]
+
+
+def nsep_default_opts():
+    L = load()
+    L.fnft_nsep_default_opts.restype = NsepOpts
+    L.fnft_nsep_default_opts.argtypes = []
+    return L.fnft_nsep_default_opts()
+
+
+def nsep_opts(d=None):
+    """NsepOpts from a dict with the keys of oracle.nsep.default_opts() (missing keys: library defaults)."""
+    o = nsep_default_opts()
+    for k, v in (d or {}).items():
+        if k == "localization":
+            o.localization = NSEP_LOC[v] if isinstance(v, str) else int(v)
+        elif k == "filtering":
+            o.filtering = NSEP_FILT[v] if isinstance(v, str) else int(v)
+        elif k == "discretization":
+            o.discretization = NSE_DISC[v] if isinstance(v, str) else int(v)
+        elif k == "bounding_box":
+            for i in range(4):
+                if v[i] is not None:
+                    o.bounding_box[i] = float(v[i])
+        elif k == "floquet_range":
+            o.floquet_range[0], o.floquet_range[1] = float(v[0]), float(v[1])
+        elif k == "tol":
+            o.tol = float(v)
+        else:
+            setattr(o, k, int(v))
+    return o
+
+
+def fnft_nsep(q, T, phase_shift=0.0, kappa=1, opts=None, K=None, M=None, want_main=True, want_aux=True,
+              sheet_indices=False):
+    """fnft_nsep() through the C ABI with host buffers.  opts: dict or NsepOpts.  K / M: capacities of the result arrays
+    (default 2*deg*D + 1 like the reference's harness).  Returns (rc, main_spec, aux_spec)."""
+    L = load()
+    L.fnft_nsep.restype = C.c_int32
+    L.fnft_nsep.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_size_t), C.c_void_p,
+                            C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(NsepOpts)]
+    q = _c128(q)
+    o = opts if isinstance(opts, NsepOpts) else nsep_opts(opts)
+    cap = 2 * 105 * q.size + 1
+    Kc = C.c_size_t(cap if K is None else int(K))
+    Mc = C.c_size_t(cap if M is None else int(M))
+    ms = np.zeros(max(Kc.value, 1), np.complex128) if want_main else None
+    au = np.zeros(max(Mc.value, 1), np.complex128) if want_aux else None
+    Tn = None if T is None else np.ascontiguousarray(T, np.float64)
+    sh = np.zeros(4) if sheet_indices else None
+    rc = L.fnft_nsep(q.size, _ptr(q), None if Tn is None else _ptr(Tn), float(phase_shift), C.byref(Kc),
+                     None if ms is None else _ptr(ms), C.byref(Mc), None if au is None else _ptr(au),
+                     None if sh is None else _ptr(sh), int(kappa), C.byref(o) if opts is not None else None)
+    return (int(rc), (ms[: Kc.value].copy() if (ms is not None and rc == 0) else None),
+            (au[: Mc.value].copy() if (au is not None and rc == 0) else None))

@@ -841,16 +841,34 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
     // argument checks in the reference's order, :53-66
     if (D == 0 || !q || !T || K == 0 || !bound_states || !a_vals || !aprime_vals) return FNFT_EC_INVALID_ARGUMENT;
     if (!skip_b_flag && !b) return FNFT_EC_INVALID_ARGUMENT;
-    if (discretization != fnft_nse_discretization_BO) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    const bool cf42 = discretization == fnft_nse_discretization_CF4_2;
+    if (discretization != fnft_nse_discretization_BO && !cf42) return FNFT_EC_NOT_YET_IMPLEMENTED;
     if (D < 2 || !(T[0] < T[1])) return FNFT_EC_INVALID_ARGUMENT;
+    if (cf42 && (D % 2 != 0 || D < 4)) return FNFT_EC_ASSERTION_FAILED;   // :188-191
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
     NftDiscSpec<HipBackend> ds(be);
     NftDiscSpec<HipBackend>::Prepared P;
-    // any 2SPLIT scheme: upsampling factor 1, the slow scatterer is BO (src/fnft_nsev.c:675-680)
-    int rc = ds.prepare(D, (const std::complex<double> *)q, T, D, (int)fnft_nse_discretization_2SPLIT4B, P, false);
+    int rc;
+    if (cf42) {
+        // CF4_2 (the scatterer fnft_nsev uses with 4SPLIT4A/B, :188-197): q holds the D preprocessed samples, two per
+        // grid point; the grid has D/2 points on T
+        P.ups = 2; P.deg0 = 4;
+        P.Deff = D; P.Dsub = D / 2;
+        P.T[0] = T[0]; P.T[1] = T[1];
+        P.eps_t = (T[1] - T[0]) / (double)(D / 2 - 1);
+        P.d_in = (cplx *)be.alloc(D * sizeof(cplx));
+        rc = P.d_in ? NFT_SUCCESS : NFT_EC_NOMEM;
+        if (rc == NFT_SUCCESS) {
+            be.h2d(P.d_in, q, D * sizeof(cplx));
+            P.d_qpre = P.d_in;
+        }
+    } else {
+        // any 2SPLIT scheme: upsampling factor 1, the slow scatterer is BO (src/fnft_nsev.c:675-680)
+        rc = ds.prepare(D, (const std::complex<double> *)q, T, D, (int)fnft_nse_discretization_2SPLIT4B, P, false);
+    }
     if (rc == NFT_SUCCESS)
         rc = ds.scatter(P, K, (const std::complex<double> *)bound_states, (std::complex<double> *)a_vals,
                         (std::complex<double> *)aprime_vals, (std::complex<double> *)b, skip_b_flag != 0);
@@ -951,7 +969,12 @@ FNFT_INT fnft__nse_scatter_matrix(const FNFT_UINT D, FNFT_COMPLEX const *const q
     // argument checks in the reference's order, :46-59
     if (D == 0 || !q || !(eps_t > 0) || (kappa != 1 && kappa != -1) || K == 0 || !lambda || !result)
         return FNFT_EC_INVALID_ARGUMENT;
-    if (discretization != fnft_nse_discretization_BO) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    // BO, and CF4_2 (two preprocessed samples per step, each advanced with lambda/2 and the whole step eps_t; the
+    // derivative picks up the factor 1/2 -- BsParams::lscale, applied by the chunk kernel:
+    // src/private/fnft__akns_scatter_matrix.c:122-130,201-208)
+    const bool cf42 = discretization == fnft_nse_discretization_CF4_2;
+    if (discretization != fnft_nse_discretization_BO && !cf42) return FNFT_EC_NOT_YET_IMPLEMENTED;
+    if (cf42 && D % 2 != 0) return FNFT_EC_ASSERTION_FAILED;
     if (current_device() < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
@@ -959,6 +982,7 @@ FNFT_INT fnft__nse_scatter_matrix(const FNFT_UINT D, FNFT_COMPLEX const *const q
     std::memset(&B, 0, sizeof(B));
     size_t L = (D + 16383) / 16384;
     if (L < 16) L = 16;
+    if (L % 2) L++;
     const size_t nchunk = (D + L - 1) / L;
     const size_t w = derivative_flag ? 8 : 4;
     cplx *dq = (cplx *)be.alloc(D * sizeof(cplx)), *dr = r ? (cplx *)be.alloc(D * sizeof(cplx)) : nullptr;
@@ -969,7 +993,8 @@ FNFT_INT fnft__nse_scatter_matrix(const FNFT_UINT D, FNFT_COMPLEX const *const q
         be.h2d(dq, q, D * sizeof(cplx));
         if (r) be.h2d(dr, r, D * sizeof(cplx));
         be.h2d(dl, lambda, K * sizeof(cplx));
-        B.q = dq; B.r = dr; B.kappa = (int)kappa; B.D = (long long)D; B.ups = 1; B.lscale = 1.0; B.eps = eps_t;
+        B.q = dq; B.r = dr; B.kappa = (int)kappa; B.D = (long long)D; B.ups = cf42 ? 2 : 1; B.lscale = cf42 ? 0.5 : 1.0;
+        B.eps = eps_t;
         B.K = (int)K; B.lam = dl; B.L = (int)L; B.nchunk = (int)nchunk; B.cm = cm; B.smat = ds;
         B.with_deriv = derivative_flag ? 1 : 0;
         for (size_t k0 = 0; k0 < K; k0 += 32768) {   // grid.y limit

@@ -216,6 +216,22 @@ public:
         be.d2h(c.data(), d_coef, (n + 1) * sizeof(cplx));
         int rc = be.sync();
         if (rc != NFT_SUCCESS) return rc;
+        {   // coefficients that are exactly zero at either end (the 12 entry of a transfer matrix with symmetric samples
+            // can have them): the degree drops -- roots at infinity -- and z = 0 is a root; the iteration runs on the rest
+            size_t nl = 0, nt = 0;
+            while (nl < n && c[nl] == cd(0, 0)) nl++;
+            while (nt < n - nl && c[n - nt] == cd(0, 0)) nt++;
+            if (nl + nt > 0) {
+                const size_t m = n - nl - nt;
+                std::vector<cd> zr;
+                rc = (m > 0) ? roots(d_coef + nl, m, zr) : NFT_SUCCESS;
+                if (rc != NFT_SUCCESS) return rc;
+                for (size_t i = 0; i < m; i++) z[i] = zr[i];
+                for (size_t i = 0; i < nl; i++) z[m + i] = cd(INFINITY, 0.0);
+                for (size_t i = 0; i < nt; i++) z[m + nl + i] = cd(0.0, 0.0);
+                return NFT_SUCCESS;
+            }
+        }
         // start values: moduli from the upper convex hull of log|c_k| (Bini), angles equispaced
         std::vector<double> la(n + 1);
         for (size_t k = 0; k <= n; k++) {

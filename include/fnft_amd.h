@@ -297,9 +297,10 @@ FNFT_INT fnft__misc_resample(const FNFT_UINT D, const FNFT_REAL eps_t, FNFT_COMP
  * replaced by Ehrlich-Aberth sweeps on the GPU; failure to converge returns -FNFT_EC_OTHER as there. */
 FNFT_INT fnft__poly_roots_fasteigen(const FNFT_UINT deg, FNFT_COMPLEX const *const p, FNFT_COMPLEX *const roots);
 
-/* include/private/fnft__nse_scatter.h:76-80 (src/private/fnft__nse_scatter_bound_states.c:29-667), BO scheme:
- * a(lambda_k), a'(lambda_k) and, unless skip_b_flag, b(lambda_k) for K points; q: D samples on [T0, T1], r is
- * not read (r = -conj(q)).  Other schemes: FNFT_EC_NOT_YET_IMPLEMENTED. */
+/* include/private/fnft__nse_scatter.h:76-80 (src/private/fnft__nse_scatter_bound_states.c:29-667), BO and CF4_2
+ * schemes (the two fnft_nsev refines with, src/fnft_nsev.c:669-676): a(lambda_k), a'(lambda_k) and, unless
+ * skip_b_flag, b(lambda_k) for K points; q: D samples on [T0, T1] (CF4_2: the D preprocessed samples, two per grid
+ * point, D even, :188-197), r is not read (r = -conj(q)).  Other schemes: FNFT_EC_NOT_YET_IMPLEMENTED. */
 FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *const q, FNFT_COMPLEX *r,
                                         FNFT_REAL const *const T, FNFT_UINT K, FNFT_COMPLEX *bound_states,
                                         FNFT_COMPLEX *a_vals, FNFT_COMPLEX *aprime_vals, FNFT_COMPLEX *b,
@@ -316,11 +317,12 @@ FNFT_INT fnft__poly_roots_fftgridsearch_paraherm(const FNFT_UINT deg, FNFT_COMPL
                                                  FNFT_UINT *const M_ptr, FNFT_REAL const *const PHI,
                                                  FNFT_COMPLEX *const roots);
 
-/* include/private/fnft__nse_scatter.h:119-123 (src/private/fnft__nse_scatter_matrix.c:33-86, BO scheme of
- * fnft__akns_scatter_matrix.c): scattering matrix S(lambda) = U_{D-1} ... U_0 of the D samples q (r = -kappa conj(q)
- * when r == NULL) with step eps_t for K values of lambda; result holds [S11 S12 S21 S22] per lambda, followed by the
- * derivatives with respect to lambda [S11' S12' S21' S22'] when derivative_flag != 0 (4K or 8K values).  Host buffers;
- * chunk-parallel on the GPU.  Other discretizations: FNFT_EC_NOT_YET_IMPLEMENTED. */
+/* include/private/fnft__nse_scatter.h:119-123 (src/private/fnft__nse_scatter_matrix.c:33-86, BO and CF4_2 schemes
+ * of fnft__akns_scatter_matrix.c:116-130): scattering matrix S(lambda) = U_{D-1} ... U_0 of the D samples q
+ * (r = -kappa conj(q) when r == NULL) with step eps_t for K values of lambda; result holds [S11 S12 S21 S22] per
+ * lambda, followed by the derivatives with respect to lambda [S11' S12' S21' S22'] when derivative_flag != 0 (4K or
+ * 8K values).  CF4_2: q holds two preprocessed samples per step (D even, FNFT_EC_ASSERTION_FAILED otherwise).  Host
+ * buffers; chunk-parallel on the GPU.  Other discretizations: FNFT_EC_NOT_YET_IMPLEMENTED. */
 FNFT_INT fnft__nse_scatter_matrix(const FNFT_UINT D, FNFT_COMPLEX const *const q, FNFT_COMPLEX *r, const FNFT_REAL eps_t,
                                   const FNFT_INT kappa, const FNFT_UINT K, FNFT_COMPLEX const *const lambda,
                                   FNFT_COMPLEX *const result, fnft_nse_discretization_t discretization,
@@ -509,6 +511,56 @@ FNFT_INT fnft_amd_kdvv_contspec_device(fnft_amd_plan_t *plan, const void *d_u, v
  * real u (no check; a non-real sample is reported by fnft_amd_plan_finish as FNFT_EC_INVALID_ARGUMENT); 0: always the
  * complex path.  The host-pointer entries fnft_kdvv / fnft__kdv_fscatter look at u on the host. */
 FNFT_INT fnft_amd_kdvv_plan_set_real_mode(fnft_amd_plan_t *plan, int mode);
+
+/* ======================================================================================== */
+/* 5. fnft_nsep: NSE with (quasi-)periodic boundary conditions           */
+/* ======================================================================================== */
+
+/* include/fnft_nsep.h:53-57 */
+typedef enum {
+    fnft_nsep_loc_SUBSAMPLE_AND_REFINE,
+    fnft_nsep_loc_GRIDSEARCH,
+    fnft_nsep_loc_MIXED
+} fnft_nsep_loc_t;
+
+/* include/fnft_nsep.h:73-77 */
+typedef enum {
+    fnft_nsep_filt_NONE,
+    fnft_nsep_filt_MANUAL,
+    fnft_nsep_filt_AUTO
+} fnft_nsep_filt_t;
+
+/* include/fnft_nsep.h:140-151 (same field order) */
+typedef struct {
+    fnft_nsep_loc_t localization;
+    fnft_nsep_filt_t filtering;
+    FNFT_REAL bounding_box[4];
+    FNFT_UINT max_evals;
+    fnft_nse_discretization_t discretization;
+    FNFT_INT normalization_flag;
+    FNFT_REAL floquet_range[2];
+    FNFT_UINT points_per_spine;
+    FNFT_UINT Dsub;
+    FNFT_REAL tol;
+} fnft_nsep_opts_t;
+
+/* include/fnft_nsep.h:172, src/fnft_nsep.c:26-39: MIXED, AUTO filtering, max_evals 20, bounding box (-inf, inf)^2,
+ * normalization on, 2SPLIT2A, floquet_range {-1, 1}, points_per_spine 2, Dsub 0 (automatic), tol -1 (automatic). */
+fnft_nsep_opts_t fnft_nsep_default_opts(void);
+
+/* Drop-in for include/fnft_nsep.h:263-268 / src/fnft_nsep.c:82-220: main and auxiliary spectrum of one period
+ * q[0..D) (D a power of two) of a quasi-periodic signal, q(t + T1 - T0) = q(t) exp(i phase_shift).  Same argument
+ * checks in the same order (sheet_indices must be NULL: FNFT_EC_NOT_YET_IMPLEMENTED otherwise), same options, same
+ * localization methods: the grid search (:222-439) builds the Floquet polynomials from fnft__nse_fscatter and finds
+ * their roots on the unit circle with fnft__poly_roots_fftgridsearch; subsample-and-refine (:441-706) takes all roots
+ * of the polynomials of a subsampled signal (fnft__poly_roots_fasteigen) and refines them by Newton's method on
+ * fnft__nse_scatter_matrix (:708-860; BO for the 2SPLIT schemes, CF4_2 for 4SPLIT4A/B) -- here all estimates advance
+ * together, one scattering-matrix call per Newton stage, each with the reference's own stopping rule.  *K_ptr / *M_ptr:
+ * capacity of main_spec / aux_spec in, number of points out.  The 21 fast discretizations are covered. */
+FNFT_INT fnft_nsep(const FNFT_UINT D, FNFT_COMPLEX const *const q, FNFT_REAL const *const T, FNFT_REAL const phase_shift,
+                   FNFT_UINT *const K_ptr, FNFT_COMPLEX *const main_spec, FNFT_UINT *const M_ptr,
+                   FNFT_COMPLEX *const aux_spec, FNFT_REAL *const sheet_indices, const FNFT_INT kappa,
+                   fnft_nsep_opts_t *opts);
 
 #ifdef __cplusplus
 }

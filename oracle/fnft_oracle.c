@@ -1150,6 +1150,50 @@ int orc_nse_scatter_bound_states(size_t D, const orc_cplx *q, const double *T, s
     return ORC_SUCCESS;
 }
 
+/* fnft__nse_scatter_matrix (src/private/fnft__nse_scatter_matrix.c:33-86 -> fnft__akns_scatter_matrix.c:112-230), BO
+ * (ups = 1) and CF4_2 (ups = 2: two preprocessed samples per step, lambda/2 per sample, derivative times 1/2):
+ * S = T_{D-1} ... T_0 with T_n = [[U, 0], [U', U]]; result: 8 values per lambda [S11 S12 S21 S22 S11' S12' S21' S22']
+ * (4 without the derivative).  r = -kappa conj(q). */
+int orc_nse_scatter_matrix(size_t D, const orc_cplx *q, double eps_t, int kappa, size_t K, const orc_cplx *lam,
+                           orc_cplx *result, int ups, int derivative)
+{
+    if (D == 0 || !q || !(eps_t > 0) || (kappa != 1 && kappa != -1) || K == 0 || !lam || !result)
+        return ORC_EC_INVALID_ARGUMENT;
+    if (ups != 1 && ups != 2) return ORC_EC_INVALID_ARGUMENT;
+    if (ups == 2 && D % 2 != 0) return ORC_EC_OTHER;
+    const double lw = (ups == 2) ? 0.5 : 1.0, scl = (ups == 2) ? 0.5 : 1.0;
+    for (size_t e = 0; e < K; e++) {
+        const orc_cplx l = lam[e] * lw;
+        orc_cplx m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0, d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;
+        for (size_t n = 0; n < D; n++) {
+            const orc_cplx qn = q[n], rn = -(double)kappa * conj(q[n]);
+            const orc_cplx ks = qn * rn - l * l, k = csqrt(ks);
+            const orc_cplx ch = ccosh(k * eps_t);
+            const orc_cplx sh = (ks != 0.0) ? csinh(k * eps_t) / k : (orc_cplx)eps_t;
+            const orc_cplx u1 = l * sh * I;
+            const orc_cplx u00 = ch - u1, u01 = qn * sh, u10 = rn * sh, u11 = ch + u1;
+            if (derivative) {
+                const orc_cplx chi = ch / ks;
+                const orc_cplx ud1 = eps_t * l * l * chi * I, ud2 = l * (eps_t * ch - sh) / ks;   /* :184-185 */
+                const orc_cplx v00 = ud1 - (l * eps_t + I + (l * l * I) / ks) * sh, v01 = -qn * ud2;
+                const orc_cplx v10 = -rn * ud2, v11 = -ud1 - (l * eps_t - I - (l * l * I) / ks) * sh;
+                const orc_cplx e00 = v00 * m00 + v01 * m10 + u00 * d00 + u01 * d10;
+                const orc_cplx e01 = v00 * m01 + v01 * m11 + u00 * d01 + u01 * d11;
+                const orc_cplx e10 = v10 * m00 + v11 * m10 + u10 * d00 + u11 * d10;
+                const orc_cplx e11 = v10 * m01 + v11 * m11 + u10 * d01 + u11 * d11;
+                d00 = e00; d01 = e01; d10 = e10; d11 = e11;
+            }
+            const orc_cplx f00 = u00 * m00 + u01 * m10, f01 = u00 * m01 + u01 * m11;
+            const orc_cplx f10 = u10 * m00 + u11 * m10, f11 = u10 * m01 + u11 * m11;
+            m00 = f00; m01 = f01; m10 = f10; m11 = f11;
+        }
+        orc_cplx *o = result + e * (derivative ? 8 : 4);
+        o[0] = m00; o[1] = m01; o[2] = m10; o[3] = m11;
+        if (derivative) { o[4] = d00 * scl; o[5] = d01 * scl; o[6] = d10 * scl; o[7] = d11 * scl; }
+    }
+    return ORC_SUCCESS;
+}
+
 /* fnft__misc.c:90-112 */
 double orc_l2norm2(size_t N, const orc_cplx *Z, double a, double b)
 {

@@ -142,6 +142,8 @@ int orc_fnft_kdvv(size_t D, const orc_cplx *u, const double *T, size_t M, orc_cp
 int orc_nse_scatter_bound_states(size_t D, const orc_cplx *q, const double *T, size_t K,
                                  const orc_cplx *lam, orc_cplx *a_vals, orc_cplx *aprime_vals,
                                  orc_cplx *b_vals, int ups, int skip_b);
+int orc_nse_scatter_matrix(size_t D, const orc_cplx *q, double eps_t, int kappa, size_t K, const orc_cplx *lam,
+                           orc_cplx *result, int ups, int derivative);
 double orc_l2norm2(size_t N, const orc_cplx *Z, double a, double b);
 
 #endif

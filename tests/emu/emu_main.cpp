@@ -185,4 +185,20 @@ int emu_nsev_discspec(size_t D, const std::complex<double> *q, const double *T, 
     return ds.run(D, q, T, o, K_ptr, bound_states, nc);
 }
 
+// all roots of a polynomial (fnft__poly_roots_fasteigen seam): the Ehrlich-Aberth kernels in the emulator.
+// *last_corr: largest relative correction of the last sweep
+int emu_poly_roots(size_t deg, const std::complex<double> *p, std::complex<double> *roots, double *last_corr)
+{
+    EmuBackend be;
+    NftDiscSpec<EmuBackend> ds(be);
+    cplx *d_coef = (cplx *)be.alloc((deg + 1) * sizeof(cplx));
+    be.h2d(d_coef, p, (deg + 1) * sizeof(cplx));
+    std::vector<std::complex<double>> z;
+    const int rc = ds.roots(d_coef, deg, z);
+    be.free(d_coef);
+    if (last_corr) *last_corr = ds.last_root_corr;
+    for (size_t i = 0; i < z.size() && i < deg; i++) roots[i] = z[i];
+    return rc;
+}
+
 }  // extern "C"

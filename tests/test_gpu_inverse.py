@@ -250,7 +250,7 @@ def test_nse_scatter_matrix_vs_oracle(capi, INV, kappa):
     assert rc == 0 and np.array_equal(res4, res[:, :4])
     rc, resr = capi.nse_scatter_matrix(q, eps, kappa, lam, r=-kappa * np.conj(q))
     assert rc == 0 and S.rel_err(resr, res) < 1e-14
-    assert capi.nse_scatter_matrix(q, eps, kappa, lam, discretization="CF4_2")[0] == 6    # not yet implemented
+    assert capi.nse_scatter_matrix(q, eps, kappa, lam, discretization="CF4_3")[0] == 6    # not yet implemented
     assert capi.nse_scatter_matrix(q, -1.0, kappa, lam)[0] == 2
 
 

@@ -888,7 +888,27 @@ def test_scatter_bound_states_bo_golden(capi, oracle, fixtures):
     # b = phi/psi is matching-point dependent at O(|a|) ~ 2e-5 where a != 0: chunked and sequential search may
     # settle on neighbouring grid points (measured 4.7e-6)
     assert np.max(np.abs(a - ao)) < 1e-14 and S.rel_err(ap, apo) < 1e-13 and S.rel_err(b, bo) < 5e-5
-    assert capi.nse_scatter_bound_states(q, T, lam, discretization="CF4_2")[0] == 6   # not covered: says so
+    assert capi.nse_scatter_bound_states(q, T, lam, discretization="CF4_3")[0] == 6   # not covered: says so
+
+
+def test_scatter_bound_states_cf4_2_vs_oracle(capi, oracle):
+    """fnft__nse_scatter_bound_states with CF4_2 through the exported symbol (the scatterer fnft_nsev refines with for
+    4SPLIT4A/B, src/private/fnft__nse_scatter_bound_states.c:188-197): the preprocessed signal (two samples per grid
+    point) of a sech pulse, a / a' / b against the oracle's sequential restatement."""
+    D, T = 512, [-12.0, 12.0]
+    q = S.sech_focusing(D, amp=3.2) if False else (3.2 / np.cosh(S.tgrid(T, D)) + 0j)
+    eps_t = (T[1] - T[0]) / (D - 1)
+    rc0, q_pre, Dsub, _ = oracle.preprocess(q, eps_t, D, "4SPLIT4B")
+    assert rc0 == 0 and q_pre.size == 2 * D
+    # at (near) eigenvalues: b = phi/psi does not depend on the matching point only where a = 0
+    lam = np.array([0.7j, 1.7j, 2.7j])
+    rc, a, ap, b = capi.nse_scatter_bound_states(q_pre, T, lam, discretization="CF4_2")
+    assert rc == 0, capi.last_error()
+    rc2, ao, apo, bo = oracle.scatter_bound_states(q_pre, T, lam, 2)
+    assert rc2 == 0
+    assert np.max(np.abs(a - ao)) < 1e-13 * max(1.0, np.max(np.abs(ao))) and S.rel_err(ap, apo) < 1e-12
+    assert S.rel_err(b, bo) < 5e-5
+    assert capi.nse_scatter_bound_states(q_pre[:-1], T, lam, discretization="CF4_2")[0] == 8   # odd D, :188-191
 
 
 def test_contspec_from_transfer_matrix_and_div_by_zero(capi, oracle):
