@@ -104,8 +104,25 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
         by = B * sum(level_bytes(D, deg0, l) for l in range(lev, lev + lv))
         gbs = by / (us * 1e-6) / 1e9 if us > 0 else 0.0
         out.append({"stage": kind, "launches": names, "levels": ([lev, lev + lv - 1] if lv else None), "us": round(us, 1),
-                    "algorithmic_bytes": by, "GB/s": round(gbs, 1), "frac": round(gbs / 8000.0, 4)})
+                    "algorithmic_bytes": by, "model_GB/s": round(gbs, 1), "model_frac": round(gbs / 8000.0, 4)})
         lev += lv
+    # chirp z-transform + epilogue (src/private/fnft__poly_chirpz.c:52-95, src/fnft_nsev.c:837-884): not part of the tree
+    # figure; its byte model is one pass of each of its three kernels over two polynomials -- N = D*deg0 + 1 coefficients
+    # in, the two length-L work arrays written and read by the column and row steps (the filter's spectrum read once), M
+    # results of nout values out
+    ch = [(n, ms) for n, ms in acc if n.startswith("KChirp")]
+    if ch:
+        names = {}
+        for n, _ in ch:
+            names[n] = names.get(n, 0) + 1
+        us = sum(ms for _, ms in ch) * 1e3
+        N, M = D * deg0 + 1, D
+        L = 1 << int(math.ceil(math.log2(N + M - 1)))
+        nout = 1 if any("true>" in n and "ColInv" in n for n in names) else 3
+        by = B * (2 * 16 * N + 2 * 16 * L + (2 * 16 * L + 16 * L + 2 * 16 * L) + 2 * 16 * L + nout * 16 * M)
+        gbs = by / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        out.append({"stage": "chirp-z + epilogue", "launches": names, "levels": None, "us": round(us, 1),
+                    "algorithmic_bytes": by, "model_GB/s": round(gbs, 1), "model_frac": round(gbs / 8000.0, 4)})
     return out
 
 
@@ -463,11 +480,19 @@ def main():
         # prescribes; profiles/traffic_from_pmc.py writes the file).  Counters cannot be read from inside
         # the process, so the number is the committed one for this workload, or null.
         traffic = None
+        traffic_note = None
         tpath = os.path.join(ROOT, "profiles", "tree_traffic.json")
         wkey = "%s/D=2^%d/%s/B=%d" % (args.workload, args.log2D, args.disc, B)
+        from fnft_amd import build as fa_build
+        bid = fa_build.build_id()
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = (json.load(f).get(wkey) or {}).get("tree_hbm_bytes_per_step")
+                ent = json.load(f).get(wkey) or {}
+            # a counter figure is only reported next to a timing of the build it was measured on
+            if ent.get("build_id") == bid:
+                traffic = ent.get("tree_hbm_bytes_per_step")
+            elif ent:
+                traffic_note = "profiles/tree_traffic.json holds counters of build %s, this is %s" % (ent.get("build_id"), bid)
         stages = launch_breakdown(plan, lambda: transform(outs[0].data_ptr()), reps, B, D, deg0)
         roof = {"bound": "hbm", "kernel": "poly_fmult2x2 tree (coefficients + all level launches of one transform)",
                 "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -475,6 +500,11 @@ def main():
                 "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
                 "chirpz_epilogue_ms": round(float(chirp_ms), 4), "stages": stages,
                 "launches_us": getattr(launch_breakdown, "last_launches", None)}
+        if traffic is not None:   # what the counters say the tree moved, as a rate (achieved / frac are the byte MODEL)
+            roof["counter_GBps"] = round(traffic / (t_tree * 1e-3) / 1e9, 1)
+            roof["counter_frac"] = round(traffic / (t_tree * 1e-3) / 1e9 / 8000.0, 4)
+        if traffic_note:
+            roof["traffic_note"] = traffic_note
         if world == 1 and not cfg5:
             # (i) cold spectral grid: `value` reuses the spectrum of the chirp filter the plan keeps between
             # calls on the same (T, XI) grids (plan data, like a twiddle table); a call on a NEW grid forms it
@@ -582,7 +612,7 @@ def main():
                                       " (configs[2]: 512 signals over 8 GPUs)" if cfg3 else ""),
                        "gather": (args.gather if world > 1 else "n/a (1 GPU)"),
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "build_id": bid,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -32,6 +32,19 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
+def build_id():
+    """Hash of the sources the library is built from (csrc/*.h, *.hip, *.c and include/fnft_amd.h): what bench.py stamps
+    its lines with and profiles/tree_traffic.json its counter figures, so that a PMC figure is only ever reported next
+    to a timing of the SAME build."""
+    import hashlib
+    h = hashlib.sha1()
+    for path in sorted([os.path.join(CSRC, s) for s in hip_sources() + C_SOURCES] + headers()):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

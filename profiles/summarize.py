@@ -33,7 +33,7 @@ def main():
             print("| %s | %s-%s | %s | %.1f | %.1f | %.1f | %.0f | %.3f |" % (
                 s["stage"], lv[0], lv[1],
                 ", ".join("%s x%d" % kc for kc in s["launches"].items()), s["us"], rp,
-                s["algorithmic_bytes"] / 1e6, s["GB/s"], s["frac"]))
+                s["algorithmic_bytes"] / 1e6, s.get("model_GB/s", s.get("GB/s")), s.get("model_frac", s.get("frac"))))
 
 
 if __name__ == "__main__":

@@ -53,7 +53,8 @@ def main():
         wk = "cfg5" if "kdvv" in wl else ("cfg3" if int(m.group(3)) > 1 else "cfg2")
         key = "%s/D=2^%s/%s/B=%s" % (wk, m.group(1), m.group(2), m.group(3))
         table[key] = {"tree_hbm_bytes_per_step": int(total), "algorithmic_bytes": line["roofline"]["algorithmic_bytes"],
-                      "tree_ms_under_profiler": line["roofline"]["tree_ms"], "per_kernel": per_kernel, "source": os.path.basename(d)}
+                      "tree_ms_under_profiler": line["roofline"]["tree_ms"], "per_kernel": per_kernel, "source": os.path.basename(d),
+                      "build_id": line.get("build_id")}
         print(key, "%.3f GB per step" % (total / 1e9))
     json.dump(table, open(path, "w"), indent=1)
 
