@@ -309,6 +309,68 @@ def bench_inverse(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+def measure_cfg3(args, rank, world, local_rank, barrier):
+    """BASELINE.json configs[2] on the ranks of this job: every rank transforms its 64 signals of D = M = 2^16 (one
+    batched plan) and the results (a, b and the reflection coefficient: 64 x 3 x 2^16 complex128 = 192 MiB per rank)
+    meet on rank 0 in one RCCL gather per batch, double-buffered so that the gather of batch i overlaps the transform of
+    batch i + 1.  Every rank runs this (the gathers are collectives); rank 0 reports it inside the one JSON line."""
+    import torch
+    import torch.distributed as dist
+    from fnft_amd import capi, sharding
+    import signals as S
+
+    D = M = 1 << 16
+    B = 64
+    T, XI = [-25.0, 25.0], [-4.0, 4.0]
+    q = np.stack([S.batch_signal(rank * B + k, D, T) for k in range(B)])
+    plan = capi.Plan(D, M, batch=B, discretization="2SPLIT2_MODAL", device=local_rank)
+    dq = torch.from_numpy(q).cuda()
+    outs = [torch.zeros(B * 3 * M, dtype=torch.complex128, device="cuda") for _ in range(2)]
+    g = sharding.ShardGather((B * 3 * M, 2), torch.float64, dst=0, depth=2)
+    stream = torch.cuda.current_stream().cuda_stream
+    steps = max(2, min(args.steps, 10))
+    dev = "cpu" if args.rehearse_gloo else "cuda"
+
+    def batch(i, gather):
+        if gather:
+            g.reserve()
+        rc = plan.contspec_device(dq.data_ptr(), outs[i % 2].data_ptr(), T, XI, kappa=1, contspec_type="BOTH",
+                                  normalization_flag=1, stream=stream)
+        if rc != 0:
+            raise RuntimeError("cfg3 batch rc=%d: %s" % (rc, capi.last_error()))
+        if gather:
+            if args.rehearse_gloo:
+                torch.cuda.synchronize()
+            g.start(torch.view_as_real(outs[i % 2]), i)
+
+    def timed(gather):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            batch(i, gather)
+        if gather:
+            g.wait()
+        barrier()
+        t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps
+
+    for i in range(2):
+        batch(i, True)
+    g.wait()
+    ms = timed(True)
+    comp = timed(False)
+    rc = plan.finish(stream)
+    plan.close()
+    if rc != 0:
+        raise RuntimeError("cfg3 device status rc=%d: %s" % (rc, capi.last_error()))
+    return {"workload": "configs[2]: %d signals of D=M=2^16 (64 per GPU), 2SPLIT2_MODAL, a, b + reflection; one gather of "
+                        "192 MiB per rank to rank 0 per batch, overlapped with the next batch" % (world * B),
+            "value": round(world * B * D / (ms * 1e-3) / 1e6, 2), "unit": "Msamples/s", "batches": steps,
+            "ms_per_batch": round(ms, 4), "compute_only_ms_per_batch": round(comp, 4),
+            "gather_overhead_ms_per_batch": round(max(0.0, ms - comp), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,7 +378,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2D", type=int, default=20)
     ap.add_argument("--disc", default="2SPLIT2_MODAL")
-    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5", "inverse"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4", "cfg5", "inverse"), default=None,
                     help="cfg2: one signal D=M=2^20 per GPU (headline); cfg3: BASELINE.json configs[2], "
                          "64 of the 512 signals D=M=2^16 per GPU; cfg4: configs[3], contspec + bound states at "
                          "D=M=2^20 through the drop-in fnft_nsev (host pointers, default options); cfg5: configs[4], "
@@ -328,10 +390,18 @@ def main():
                          "timed region (RCCL, overlapped with the next step's compute); 'job' = only the last "
                          "step's shards are gathered; 'none' = results stay sharded")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--gather-parts", choices=("rho", "ab", "both"), default="both",
+                    help="N>1: which part of every signal's result the per-step gather moves to rank 0: the reflection "
+                         "coefficient (M values), a and b (2M), or all three (3M, default).  At N = 8 and D = 2^20 'both' asks "
+                         "rank 0 to take in 7 x 48 MiB per 0.73 ms step -- about the one-directional rate of its xGMI links; "
+                         "'rho' (the library's default contspec_type) is a third of that")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 control-flow rehearsal on a box with fewer GPUs than ranks: gloo backend, "
                          "host-staged gather, ranks share the visible GPUs (not a measurement)")
     args = ap.parse_args()
+    workload_given = args.workload is not None
+    if args.workload is None:
+        args.workload = "cfg2"
 
     import torch
     import torch.distributed as dist
@@ -393,10 +463,19 @@ def main():
     # N > 1: the result shards meet on rank 0 through the product's sharding module (fnft_amd/sharding.py):
     # device tensors into RCCL under nccl; under the gloo rehearsal the same calls stage through the host
     gatherer = None
+    part = (0, nout) if nout == 1 else {"rho": (0, 1), "ab": (1, 3), "both": (0, 3)}[args.gather_parts]
+    npart = part[1] - part[0]
     if world > 1 and args.gather != "none":
         from fnft_amd import sharding
-        gatherer = sharding.ShardGather((B * nout * M, 2), torch.float64, dst=0, depth=2)
+        gatherer = sharding.ShardGather((B * npart * M, 2), torch.float64, dst=0, depth=2)
     stream = torch.cuda.current_stream().cuda_stream
+
+    def shard_of(buf):
+        """the part of a result buffer ([signal][rho | a | b][M]) the gather moves, as a real [n, 2] tensor"""
+        if npart == nout:
+            return torch.view_as_real(buf)
+        sel = buf.view(B, nout, M)[:, part[0]:part[1], :]
+        return torch.view_as_real(sel.contiguous().view(-1))
 
     def transform(out_ptr):
         if cfg5:
@@ -415,7 +494,7 @@ def main():
             if args.rehearse_gloo:
                 torch.cuda.synchronize()   # gloo copies through the host: the kernels must have finished
             # nccl: the collective is ordered behind this step's kernels (same current stream)
-            gatherer.start(torch.view_as_real(buf), i)
+            gatherer.start(shard_of(buf), i)
 
     def barrier():
         torch.cuda.synchronize()
@@ -460,6 +539,30 @@ def main():
     wall_ms_max = float(t_all.item())
     ms_per_step = wall_ms_max / args.steps
     value = world * B * D / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
+
+    # ---- N > 1: what the gather costs, and BASELINE.json configs[2] in the same run ------------------------
+    multi = {}
+    if world > 1 and gatherer is not None and args.gather == "step":
+        # the same K steps with the results left on their GPUs: the difference is the collective's share of a step
+        barrier()
+        tc0 = time.perf_counter()
+        for i in range(args.steps):
+            if transform(outs[i % 2].data_ptr()) != 0:
+                raise RuntimeError("compute-only step: %s" % capi.last_error())
+        barrier()
+        t_c = torch.tensor([(time.perf_counter() - tc0) * 1e3], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
+        dist.all_reduce(t_c, op=dist.ReduceOp.MAX)
+        comp = float(t_c.item()) / args.steps
+        multi = {"gather_parts": args.gather_parts if nout == 3 else "rho",
+                 "gather_bytes_per_rank_per_step": B * npart * M * 16,
+                 "compute_only_ms_per_step": round(comp, 4),
+                 "gather_overhead_ms_per_step": round(max(0.0, ms_per_step - comp), 4)}
+        if plan.finish(stream) != 0:
+            raise RuntimeError("device status: %s" % capi.last_error())
+    if world > 1 and not workload_given and args.gather != "none":
+        # the driver's scaling command passes no --workload: next to the headline (one 2^20 signal per GPU) it also gets
+        # configs[2] -- 64 signals of 2^16 per GPU, one gather of every GPU's results per batch -- as "cfg3"
+        multi["cfg3"] = measure_cfg3(args, rank, world, local_rank, barrier)
 
     # ---- tree-only timing with HIP events over many passes (roofline) -----------------------
     roof = None
@@ -614,6 +717,8 @@ def main():
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
             "roofline": roof, "cpu_baseline": cpu, "build_id": bid,
         }
+        if multi:
+            line["multi_gpu"] = multi
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

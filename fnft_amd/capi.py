@@ -102,7 +102,7 @@ EXPORTED = [
     "fnft__nse_scatter_matrix", "fnft__poly_roots_fftgridsearch", "fnft__poly_roots_fftgridsearch_paraherm",
     "fnft_kdvv", "fnft_kdvv_default_opts", "fnft__kdv_fscatter_numel", "fnft__kdv_fscatter",
     "fnft_amd_kdvv_plan_create", "fnft_amd_kdvv_contspec_device", "fnft_amd_kdvv_plan_set_real_mode",
-    "fnft_amd_release_cached", "fnft_nsep", "fnft_nsep_default_opts",
+    "fnft_amd_release_cached", "fnft_nsep", "fnft_nsep_default_opts", "fnft_amd_poly_fmult2x2_device",
 ]
 
 _lib = None
@@ -745,6 +745,19 @@ class Plan:
         rc = self.L.fnft_amd_plan_get_transfer_matrix(self.h, b, _ptr(buf), C.byref(deg), C.byref(W))
         d = deg.value
         return int(rc), d, buf[: 4 * (d + 1)].reshape(4, d + 1).copy(), int(W.value)
+
+
+def poly_fmult2x2_device(deg, n, p_ptr, out_ptr, stream=0):
+    """fnft_amd_poly_fmult2x2_device: n matrices of degree deg in device memory (reference input layout) -> their product
+    in device memory (reference result layout, normalised).  Returns (rc, deg_out, W)."""
+    L = load()
+    L.fnft_amd_poly_fmult2x2_device.restype = C.c_int32
+    L.fnft_amd_poly_fmult2x2_device.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t),
+                                                C.POINTER(C.c_int32), C.c_void_p]
+    d, W = C.c_size_t(0), C.c_int32(0)
+    rc = L.fnft_amd_poly_fmult2x2_device(int(deg), int(n), C.c_void_p(p_ptr), C.c_void_p(out_ptr), C.byref(d), C.byref(W),
+                                         C.c_void_p(stream))
+    return int(rc), int(d.value), int(W.value)
 
 
 def release_cached(device=-1):

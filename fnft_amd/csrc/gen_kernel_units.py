@@ -16,7 +16,7 @@ PF = [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 groups = {}
 g = ["KCoeffs<%d>" % d for d in (1, 2, 3, 4)]
 g += ["KCoeffsProg", "KResamplePhase", "KResampleCombine", "KBandCheck", "KBsChunk<false>", "KBsChunk<true>", "KBsCombine<false>",
-      "KBsCombine<true>", "KBsPhi", "KBsMetric", "KBsPick", "KBsPsi", "KBsMatrix", "KGridMark", "KGridMarkPh", "KCompactCount", "KCompactScatter", "KInvOp", "KInvSolitons", "KInvCdt", "KPeelImport", "KPeelLeaf", "KPeelProduct<512>", "KPeelProduct<1024>", "KPeelProduct<2048>", "KAberthNewton", "KAberthSum", "KAberthApply", "KFinalizeScales", "KExportTm"]
+      "KBsCombine<true>", "KBsPhi", "KBsMetric", "KBsPick", "KBsPsi", "KBsMatrix", "KGridMark", "KGridMarkPh", "KCompactCount", "KCompactScatter", "KInvOp", "KInvSolitons", "KInvCdt", "KPeelImport", "KPeelLeaf", "KPeelProduct<512>", "KPeelProduct<1024>", "KPeelProduct<2048>", "KAberthNewton", "KAberthSum", "KAberthApply", "KFinalizeScales", "KExportTm", "KImportLevel0"]
 g += ["KLeaf<%d>" % d for d in (1, 2, 3, 4)] + ["KPairSchool<%d>" % d for d in (1, 2, 3)]
 groups["misc"] = g
 groups["pair4a"] = ["KPairFft<%d, 4>" % n for n in PF if n <= 256]

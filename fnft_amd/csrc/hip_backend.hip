@@ -537,6 +537,35 @@ FNFT_INT fnft__poly_fmult2x2(FNFT_UINT *const d, FNFT_UINT n, FNFT_COMPLEX *cons
     return api_poly_fmult2x2(be, d, n, p, result, W_ptr);
 }
 
+// fnft__poly_fmult2x2 on matrices that are already in device memory (the root's step of a sample-axis split: the G
+// block matrices arrive by RCCL): d_p holds n matrices of degree deg in the reference's input layout, d_result
+// (4 * (n*deg + 1) complex128) receives the product in the reference's result layout, normalised; *W_out its exponent.
+// Runs on `stream` of the calling thread's current device; waits for the stream once (W is read back).
+FNFT_INT fnft_amd_poly_fmult2x2_device(FNFT_UINT deg, FNFT_UINT n, const void *d_p, void *d_result, FNFT_UINT *deg_out,
+                                       FNFT_INT *W_out, void *stream)
+{
+    if (deg == 0 || n == 0 || !d_p || !d_result || !W_out || deg > 0x7fffffff) return FNFT_EC_INVALID_ARGUMENT;
+    if (current_device() < 0) return FNFT_EC_OTHER;
+    std::lock_guard<std::mutex> host_lk(host_call_mutex());
+    HipBackend be;
+    be.stream = (hipStream_t)stream;
+    Plan pl(be, n, 0, 1, -1, (int)deg);
+    int rc = pl.init();
+    if (rc == NFT_SUCCESS) rc = pl.load_level0_from_device(d_p);
+    if (rc == NFT_SUCCESS) rc = pl.run_tree();
+    if (rc == NFT_SUCCESS) {
+        pl.export_tm((cplx *)d_result, (size_t)(pl.res_deg + 1), false);
+        int W = 0;
+        be.d2h(&W, pl.wexp[pl.cur], sizeof(int));
+        rc = be.sync();
+        *W_out = W;
+        if (deg_out) *deg_out = pl.res_deg;
+    }
+    pl.destroy();
+    if (be.failed) return FNFT_EC_OTHER;
+    return rc;
+}
+
 // ---- scalar products and single pair products (src/private/fnft__poly_fmult.c:35-38,45-121,152-328) ----------
 // They ride on the 2x2 tree: a scalar polynomial p is the matrix diag(p, p), whose products have the scalar
 // product in entry 11.

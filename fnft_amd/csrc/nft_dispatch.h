@@ -189,6 +189,12 @@ struct KFinalizeScales {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_finalize_scales(p); }
 };
+struct KImportLevel0 {
+    using Params = ImportParams;
+    static constexpr int THREADS = 256;
+    static constexpr size_t lds_bytes() { return 0; }
+    static FA_DEV void body(const Params &p) { body_import_level0(p); }
+};
 struct KExportTm {
     using Params = ExportParams;
     static constexpr int THREADS = 256;

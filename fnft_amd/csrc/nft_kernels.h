@@ -1963,6 +1963,34 @@ FA_DEV void body_finalize_scales(const TreeLevel &L)
 }
 
 // ---------------------------------------------------------------------------------------------
+// level 0 of a tree from n coefficient matrices that are already in DEVICE memory in the reference's input layout
+// (fnft__poly_fmult.c:398-401: entry-major, matrix j of the product at p[e*n*(deg+1) + j*(deg+1) + k]) -- the body/tail
+// layout of this file, identity padding z^deg * I up to the power of two (:422-438), scale 1, exponent 0
+struct ImportParams {
+    const cplx *p;
+    cplx *body, *tail;
+    double *scale;
+    int *wexp;
+    size_t plane;
+    long long n, npad, deg;
+};
+FA_DEV void body_import_level0(const ImportParams &P)
+{
+    const long long i = (long long)FA_BID * FA_BDIM + FA_TID;
+    const long long w = P.deg + 1;
+    if (i >= 4 * P.npad * w) return;
+    const int e = (int)(i / (P.npad * w));
+    const long long r = i % (P.npad * w);
+    const long long j = r / w, k = r % w;
+    cplx v = cmake(0.0, 0.0);
+    if (j < P.n) v = P.p[(long long)e * P.n * w + j * w + k];
+    else if (k == 0 && (e == 0 || e == 3)) v = cmake(1.0, 0.0);
+    if (k < P.deg) P.body[(size_t)e * P.plane + (size_t)(j * P.deg + k)] = v;
+    else P.tail[(size_t)e * P.npad + j] = v;
+    if (e == 0 && k == 0) { P.scale[j] = 1.0; P.wexp[j] = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // final transfer matrix in the reference's result layout (fnft__poly_fmult.c:522-538):
 // [r11|r12|r21|r22], each deg+1 coefficients, highest power first; deg = D*deg0 (the identity
 // padding contributes trailing zero coefficients which are dropped).

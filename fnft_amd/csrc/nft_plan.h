@@ -517,6 +517,24 @@ public:
     }
 
     // ---- product tree (fnft__poly_fmult.c:460-519) ---------------------------------------------
+    // ---- level 0 from coefficient matrices in DEVICE memory (reference layout, D matrices of degree deg0) ------
+    int load_level0_from_device(const void *d_p)
+    {
+        ImportParams I;
+        I.p = (const cplx *)d_p;
+        I.body = body[0]; I.tail = tail[0]; I.scale = scale[0]; I.wexp = wexp[0];
+        I.plane = plane;
+        I.n = (long long)D; I.npad = (long long)Dpad; I.deg = (long long)deg0;
+        const long long tot = 4 * I.npad * (I.deg + 1);
+        be.template run<KImportLevel0>((int)((tot + 255) / 256), 1, I);
+        cur = 0;
+        ne = 4;
+        real_run = false;
+        start_n = n0;
+        start_d = (size_t)deg0;
+        return NFT_SUCCESS;
+    }
+
     // the same tree on real coefficients (nft_real.h): folded transforms of length M = nft_real_len(d)
     int run_tree_real()
     {

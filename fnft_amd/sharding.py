@@ -346,6 +346,38 @@ def plan_sample_axis_engine(discretization: str, kappa: int, deg0: int) -> Sampl
 
     eng = SampleAxisEngine(subtree, host.combine, host.chirpz, deg0, host.shifted)
     eng.plans = plans
+
+    def device_root(rows, d, D, T, XI, M):
+        """The root's step with everything on the GPU: rows [G, 8(d+1)+1] float64 CUDA tensor (the gathered block
+        matrices and their exponents) -> [rho | a | b] as a complex128 CUDA tensor.  The product of the G matrices is
+        fnft_amd_poly_fmult2x2_device (the last block of samples is the leftmost factor), the evaluation
+        fnft_amd_nsev_contspec_from_tm_device."""
+        G = int(rows.shape[0])
+        dev = rows.device
+        Ws = [int(w) for w in rows[:, -1].cpu().tolist()]
+        tms = torch.view_as_complex(rows[:, :-1].contiguous().view(G, 4, d + 1, 2))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if G == 1:
+            tm_all, Wc = tms[0].contiguous(), 0
+        else:
+            p = torch.stack([torch.cat([tms[G - 1 - j, e] for j in range(G)]) for e in range(4)]).contiguous()
+            tm_all = torch.zeros((4, G * d + 1), dtype=torch.complex128, device=dev)
+            rc, dd, Wc = capi.poly_fmult2x2_device(d, G, p.data_ptr(), tm_all.data_ptr(), stream)
+            if rc != 0 or dd != G * d:
+                raise RuntimeError("fnft_amd_poly_fmult2x2_device rc=%d deg=%d (%s)" % (rc, dd, capi.last_error()))
+        di = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = ("root", D, M, di)
+        if key not in plans:
+            plans[key] = capi.Plan(D, M, batch=1, discretization=discretization, device=di)
+        out = torch.zeros(3 * M, dtype=torch.complex128, device=dev)
+        rc = plans[key].contspec_from_tm_device(tm_all.data_ptr(), sum(Ws) + Wc, out.data_ptr(), T, XI, "BOTH", stream)
+        if rc == 0:
+            rc = plans[key].finish(stream)
+        if rc != 0:
+            raise RuntimeError("fnft_amd_nsev_contspec_from_tm_device rc=%d (%s)" % (rc, capi.last_error()))
+        return out
+
+    eng.device_root = device_root
     return eng
 
 
@@ -431,6 +463,9 @@ def transform_sample_axis(q: Optional[np.ndarray], T, XI, M: int, eng: SampleAxi
     full = gather_shards(row, world, dst=dst, group=group)
     if full is None:
         return None
+    if data_device is not None and getattr(eng, "device_root", None) is not None and full.is_cuda:
+        # block matrices arrived device-to-device: product and evaluation on the root's GPU, only the result leaves it
+        return eng.device_root(full, d, D, T, XI, M).cpu().numpy()
     rows = full.cpu().numpy()
     Ws = [int(rows[g, -1]) for g in range(world)]
     tms = [np.ascontiguousarray(rows[g, :-1]).view(np.complex128).reshape(4, d + 1) for g in range(world)]

@@ -373,6 +373,12 @@ void fnft_amd_release_cached(int device);
  * discretization.  Allocates every workspace the call needs in HBM once. */
 FNFT_INT fnft_amd_plan_create(fnft_amd_plan_t **plan, FNFT_UINT D, FNFT_UINT M, FNFT_UINT batch,
                               fnft_nse_discretization_t discretization, int device);
+/* fnft__poly_fmult2x2 (src/private/fnft__poly_fmult.c:381-546) on DEVICE buffers: d_p holds n matrices of degree deg in
+ * the reference's input layout [4][n*(deg+1)], d_result (4*(n*deg+1) complex128) receives [r11|r12|r21|r22] normalised,
+ * *W_out the exponent (true product = result * 2^W).  On `stream` of the current device; waits for it once.  This is the
+ * root's step of a sample-axis split: the block matrices arrive by RCCL and never visit the host. */
+FNFT_INT fnft_amd_poly_fmult2x2_device(FNFT_UINT deg, FNFT_UINT n, const void *d_p, void *d_result, FNFT_UINT *deg_out,
+                                       FNFT_INT *W_out, void *stream);
 /* same, for the second (coarse) transform of Richardson extrapolation with 4SPLIT4A/B: the
  * transform uses every nskip-th step of the D samples; the band-limited resampling of
  * fnft__nse_discretization_preprocess_signal (src/private/fnft__nse_discretization.c:474-503)

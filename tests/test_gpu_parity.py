@@ -911,6 +911,40 @@ def test_scatter_bound_states_cf4_2_vs_oracle(capi, oracle):
     assert capi.nse_scatter_bound_states(q_pre[:-1], T, lam, discretization="CF4_2")[0] == 8   # odd D, :188-191
 
 
+@pytest.mark.parametrize("deg,n", [(1, 4), (3, 5), (64, 8), (1000, 3), (4096, 2), (2048, 16)])
+def test_poly_fmult2x2_device_vs_host_seam(capi, deg, n):
+    """fnft_amd_poly_fmult2x2_device (factors and product in device memory: the root's step of a sample-axis split)
+    against fnft__poly_fmult2x2 on the same matrices through host buffers: the same tree, so the same numbers."""
+    import torch
+    rng = np.random.default_rng(deg + n)
+    p = (rng.standard_normal((4, n * (deg + 1))) + 1j * rng.standard_normal((4, n * (deg + 1)))) / np.sqrt(deg + 1)
+    rc, d0, ref, W0 = capi.poly_fmult2x2(deg, n, p.copy())
+    assert rc == 0 and d0 == n * deg
+    dp = torch.from_numpy(p).cuda()
+    out = torch.zeros((4, n * deg + 1), dtype=torch.complex128, device="cuda")
+    rc, d1, W1 = capi.poly_fmult2x2_device(deg, n, dp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, capi.last_error()
+    assert (d1, W1) == (d0, W0)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert capi.poly_fmult2x2_device(0, n, dp.data_ptr(), out.data_ptr())[0] == 2
+
+
+def test_release_cached_keeps_results(capi):
+    """fnft_amd_release_cached: cached plans, the resident layer-peeling state and the cache of released device blocks go
+    back to the driver; the next call rebuilds what it needs and returns the same numbers."""
+    D, M = 4096, 512
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    q = S.sech_focusing(D)
+    rc, a = capi.fnft_nsev(q, T, M, XI, discretization="2SPLIT4B", contspec_type="BOTH")
+    assert rc == 0
+    capi.release_cached(-1)
+    rc, b = capi.fnft_nsev(q, T, M, XI, discretization="2SPLIT4B", contspec_type="BOTH")
+    assert rc == 0 and np.array_equal(a, b)
+    capi.release_cached(0)
+    rc, c = capi.fnft_nsev(q, T, M, XI, discretization="2SPLIT4B", contspec_type="BOTH")
+    assert rc == 0 and np.array_equal(a, c)
+
+
 def test_contspec_from_transfer_matrix_and_div_by_zero(capi, oracle):
     """nsev_compute_contspec on a caller-supplied transfer matrix (fnft_amd_nsev_contspec_from_tm_device):
     (i) fed with the plan's own transfer matrix it reproduces the spectrum of the full call; (ii) a transfer
