@@ -39,8 +39,13 @@ FNFT_INT fnft_kdvv(const FNFT_UINT D, FNFT_COMPLEX *const u, FNFT_REAL const *co
         return E_NOT_YET_IMPLEMENTED(normconsts_or_residues, "Please pass \"NULL\".");
     if (opts_ptr == NULL) opts_ptr = &default_opts;
 
-    const int kd = (int)opts_ptr->discretization;
-    if (kd < 0 || kd > (int)fnft_kdv_discretization_CF6_4) {
+    int kd = (int)opts_ptr->discretization;
+    /* 4SPLIT4A / 4SPLIT4B: the reference's fnft_kdvv hands the RAW samples to kdv_fscatter (no resampling, :108-113),
+     * where these two use the per-sample formulas and degrees of 2SPLIT4A / 2SPLIT4B
+     * (src/private/fnft__kdv_discretization.c:139-143, fnft__akns_fscatter.c:362-363,402-403): the same transform */
+    if (kd == (int)fnft_kdv_discretization_4SPLIT4A) kd = (int)fnft_kdv_discretization_2SPLIT4A;
+    if (kd == (int)fnft_kdv_discretization_4SPLIT4B) kd = (int)fnft_kdv_discretization_2SPLIT4B;
+    if ((int)opts_ptr->discretization < 0 || (int)opts_ptr->discretization > (int)fnft_kdv_discretization_CF6_4) {
         /* kdv_fscatter_numel returns 0 and kdv_fscatter raises, src/fnft_kdvv.c:100-113 */
         FNFT_INT rc = E_INVALID_ARGUMENT(discretization);
         return E_SUBROUTINE(rc);

@@ -1083,9 +1083,18 @@ FNFT_INT fnft__nse_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q, cons
     return api_akns_fscatter(be, D, q, nullptr, eps_t, kappa, result, deg_ptr, W_ptr, a);
 }
 
+// 4SPLIT4A / 4SPLIT4B of the KdV seams: per-sample formulas and degrees of 2SPLIT4A / 2SPLIT4B on the samples as they
+// are (src/private/fnft__kdv_discretization.c:139-143; kdv_fscatter does not resample)
+static int kdv_alias(int kd)
+{
+    if (kd == (int)fnft_kdv_discretization_4SPLIT4A) return (int)fnft_kdv_discretization_2SPLIT4A;
+    if (kd == (int)fnft_kdv_discretization_4SPLIT4B) return (int)fnft_kdv_discretization_2SPLIT4B;
+    return kd;
+}
+
 FNFT_UINT fnft__kdv_fscatter_numel(FNFT_UINT D, fnft_kdv_discretization_t discretization)
 {
-    const int kd = (int)discretization;
+    const int kd = kdv_alias((int)discretization);
     if (kd < 0 || kd > (int)fnft_kdv_discretization_2SPLIT8B) return 0;
     return fnft__poly_fmult2x2_numel((FNFT_UINT)nft_akns_degree(kd + 1), D);
 }
@@ -1096,7 +1105,7 @@ FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, cons
                             fnft_kdv_discretization_t discretization)
 {
     if (D == 0 || !u || !(eps_t > 0.0) || !result || !deg_ptr) return FNFT_EC_INVALID_ARGUMENT;
-    const int kd = (int)discretization;
+    const int kd = kdv_alias((int)discretization);
     if (kd < 0 || kd > (int)fnft_kdv_discretization_2SPLIT8B) return FNFT_EC_INVALID_ARGUMENT;
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;

@@ -322,6 +322,31 @@ public:
 #endif
                 if (mc < kAberthTol) break;
             }
+            // polish (AberthParams::polish): two plain Newton steps on every estimate, half the work of a sweep each.
+            // eiscor's QR (fnft__poly_roots_fasteigen.c:29-48) is backward stable; this brings clustered roots from the
+            // sweeps' worst-case stopping level to what the conditioning of the polynomial allows
+            if (rc == NFT_SUCCESS && mc < kAberthFail) {
+                be.h2d(ibuf[0], ident.data(), n * sizeof(int));
+                for (int it = 0; it < 2; it++) {
+                    A.z = zbuf[cur];
+                    A.z_out = zbuf[cur ^ 1];
+                    A.idx = ibuf[0];
+                    A.idx_out = ibuf[1];
+                    A.na = (long long)n;
+                    A.polish = 1;
+                    const int gx = (int)((n + 255) / 256);
+                    size_t S = (BE::kTargetWorkgroups + (size_t)gx - 1) / (size_t)gx;
+                    if (S > kSegCap) S = kSegCap;
+                    if (n < 128 || S < 1) S = 1;
+                    A.S = (int)S;
+                    A.L = (long long)(((n + 1 + S - 1) / S + 7) / 8 * 8);
+                    A.J = (long long)((n + S - 1) / S);
+                    be.memset0(d_state, 2 * sizeof(unsigned long long));
+                    be.template run<KAberthNewton>(gx, (int)S, A);
+                    be.template run<KAberthApply>(gx, 1, A);
+                    cur ^= 1;
+                }
+            }
             if (rc == NFT_SUCCESS) {
                 be.d2h(z.data(), zbuf[cur], n * sizeof(cplx));
                 rc = be.sync();

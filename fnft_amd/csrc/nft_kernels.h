@@ -3437,6 +3437,11 @@ struct AberthParams {
     int *idx_out;
     int *cnt;
     long long na;
+    // polish != 0 (after the iteration has converged): one plain Newton step per estimate -- no repulsion sum (ps is not
+    // read), no freezing at the evaluation-noise bound, steps limited to 1e-3 (1 + |z|).  The bound of the sweeps is a
+    // worst-case one; inside a cluster of roots it stops the estimates a factor ~10 further out than the polynomial's
+    // conditioning allows, and Newton's method converges quadratically from there (the neighbours are 100x further away).
+    int polish = 0;
 };
 
 // p(x) = sum_r x^r P_r(x^NCH): NCH independent Horner chains (plus their derivatives and the |coefficient| chains
@@ -3643,14 +3648,14 @@ FA_DEV void body_aberth_apply(const AberthParams &P)
             q = q * xL + P.pp[o];
             d = d * xL + P.pd[o];
             escale = fma(escale, axL, P.pe[o]);
-            s = s + P.ps[o];
+            if (!P.polish) s = s + P.ps[o];
         }
         const cplx p = q;
         const cplx dp = d + (xL1 * dq) * (double)P.L;
         // |p(x)| at the level of its own evaluation error (running error bound of Horner's scheme, statistical
         // sqrt(n) growth): the estimate is a root to working accuracy and is left alone -- without this, roots of
         // an ill-conditioned polynomial keep receiving corrections of the size of the noise and never "converge"
-        const double noise = 2.220446049250313e-16 * (2.0 * sqrt((double)n) + 2.0) * escale;
+        const double noise = P.polish ? 0.0 : 2.220446049250313e-16 * (2.0 * sqrt((double)n) + 2.0) * escale;
         cplx w;
         if (cnorm2(p) <= noise * noise) {
             w = cmake(0.0, 0.0);
@@ -3662,10 +3667,11 @@ FA_DEV void body_aberth_apply(const AberthParams &P)
             w = c_div(cmake(1.0, 0.0), t);
         }
         if (!(w.x == w.x) || !(w.y == w.y) || fabs(w.x) > 1.0e300 || fabs(w.y) > 1.0e300) w = cmake(0.0, 0.0);
-        const bool hit = P.hit[k] != 0;
-        P.hit[k] = 0;
+        const bool hit = !P.polish && P.hit[k] != 0;
+        if (!P.polish) P.hit[k] = 0;
         cplx corr = c_div(w, cmake(1.0, 0.0) - w * s);
         const double az0 = sqrt(cnorm2(zk));
+        if (P.polish && !(cnorm2(corr) <= 1.0e-6 * (1.0 + az0) * (1.0 + az0))) corr = cmake(0.0, 0.0);   // NaN or not small
         if (hit) {   // coincident estimates: separate them (different steps for different k)
             const double h = 1.0e-8 * (1.0 + az0);
             corr = corr + cmake(h * (1.0 + (double)(k & 7)), -0.5 * h * (1.0 + (double)((k >> 3) & 7)));

@@ -202,6 +202,10 @@ def test_bench_launch_breakdown_assigns_every_level_once():
 
     D = 1 << 20
     st = bench.launch_breakdown(FakePlan(), lambda: None, 2, 1, D, 1, sync=lambda: None)
-    assert [s["levels"] for s in st] == [[0, 5], [6, 8], [9, 11], [12, 19]]
-    assert sum(s["algorithmic_bytes"] for s in st) == bench.bytes_tree(D, 1) == 2885680960
-    assert st[-1]["launches"]["KMid<2>"] == 8 and "KChirpRows" not in st[-1]["launches"]
+    tree, chirp = st[:-1], st[-1]
+    assert [s["levels"] for s in tree] == [[0, 5], [6, 8], [9, 11], [12, 19]]
+    assert sum(s["algorithmic_bytes"] for s in tree) == bench.bytes_tree(D, 1) == 2885680960
+    assert tree[-1]["launches"]["KMid<2>"] == 8 and "KChirpRows" not in tree[-1]["launches"]
+    # the chirp z-transform and the epilogue are a stage of their own (not part of the tree's byte figure)
+    assert chirp["stage"] == "chirp-z + epilogue" and chirp["levels"] is None and set(chirp["launches"]) == set(FakePlan.seq[-3:])
+    assert all("model_frac" in s and "frac" not in s for s in st)

@@ -298,14 +298,16 @@ def test_full_size_2p20_analytic(capi, disc, order_bound, floor):
     assert np.max(np.abs(inv - 1.0)) < 1e-7
 
 
-def test_full_size_2p20_vs_oracle(capi, oracle):
-    """cfg 2 against the CPU oracle at the full size (about 15 s of CPU): MODAL, a, b and rho."""
+@pytest.mark.parametrize("disc", ["2SPLIT2_MODAL", "2SPLIT4B"])
+def test_full_size_2p20_vs_oracle(capi, oracle, disc):
+    """cfg 2 against the CPU oracle at the full size (5 s of CPU for MODAL, 10 s for the library's default 2SPLIT4B):
+    a, b and rho."""
     D = M = 1 << 20
     T, XI = [-25.0, 25.0], [-7.0 / 5.0, 8.0 / 5.0]
     q = S.sech_focusing(D)
-    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, discretization="2SPLIT2_MODAL", contspec_type="BOTH")
+    rc, cs = capi.fnft_nsev(q, T, M, XI, kappa=1, discretization=disc, contspec_type="BOTH")
     assert rc == 0, capi.last_error()
-    rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc="2SPLIT2_MODAL", cstype="BOTH")
+    rc2, ref = oracle.fnft_nsev(q, T, M, XI, kappa=1, disc=disc, cstype="BOTH")
     assert rc2 == 0
     tol = tol_for(D)
     for k in range(3):
@@ -520,6 +522,25 @@ def test_kdv_fscatter_real_tree_exports_reference_layout(capi, oracle):
         rc2, deg2, ref, W2 = oracle.kdv_fscatter(u, eps_t, disc, normalize=True)
         assert rc2 == 0 and deg == deg2
         assert _tm_err(tm, W, ref, W2) < 1e-11
+
+
+def test_kdvv_4split4_is_2split4_on_raw_samples(capi, oracle):
+    """fnft_kdvv / fnft__kdv_fscatter with 4SPLIT4A/B: the reference maps them to the AKNS schemes of the same name
+    (src/private/fnft__kdv_discretization.c:139-143) and kdv_fscatter hands the samples over as they are, where those
+    schemes share formulas and degree with 2SPLIT4A/B (fnft__akns_fscatter.c:362-363,402-403): identical results."""
+    D, M = 1024, 256
+    T, XI = [-16.0, 15.0], [-3.0, 3.5]
+    u = 0.8 * S.kdvv_sech(D, T)
+    for four, two in (("4SPLIT4A", "2SPLIT4A"), ("4SPLIT4B", "2SPLIT4B")):
+        rc, a = capi.fnft_kdvv(u, T, M, XI, discretization=four)
+        rc2, b = capi.fnft_kdvv(u, T, M, XI, discretization=two)
+        assert rc == 0 and rc2 == 0 and np.array_equal(a, b)
+        rc3, ref = oracle.fnft_kdvv(u, T, M, XI, two)
+        assert rc3 == 0 and S.rel_err(a, ref) < 2e-11
+        eps_t = (T[1] - T[0]) / (D - 1)
+        r1 = capi.kdv_fscatter(u, eps_t, four)
+        r2 = capi.kdv_fscatter(u, eps_t, two)
+        assert r1[0] == 0 and r1[1] == r2[1] and np.array_equal(r1[2], r2[2]) and r1[3] == r2[3]
 
 
 def test_kdvv_argument_errors(capi):
@@ -850,7 +871,8 @@ def test_poly_roots_fasteigen_golden(capi, fixtures):
     rng = np.random.default_rng(5)
     known = np.concatenate([0.9 * np.exp(2j * np.pi * rng.random(50)), 1.3 * np.exp(2j * np.pi * rng.random(50))])
     rc, r = capi.poly_roots_fasteigen(np.poly(known))
-    assert rc == 0 and _hausdorff(r, known) < 5e-6     # conditioning of np.poly coefficients; sweeps stop at the evaluation-noise level
+    # conditioning of np.poly's coefficients: LAPACK's backward-stable roots of the same coefficients are 2.6e-8 away
+    assert rc == 0 and _hausdorff(r, known) < 1e-7
     # 600 well-conditioned roots, known exactly: (z^300 - a)(z^300 - b), two circles of radius 0.9 and 1.3
     n = 300
     known = np.concatenate([0.9 * np.exp(2j * np.pi * (np.arange(n) + 0.3) / n),
@@ -862,11 +884,13 @@ def test_poly_roots_fasteigen_golden(capi, fixtures):
     assert rc == 0 and _hausdorff(r, known) < 1e-12
     clustered = np.array([0.5 + 0.5j, 0.5 + 0.5j + 1e-4, 0.5 + 0.5j - 1e-4j, -0.3j, 2.0])
     rc, r = capi.poly_roots_fasteigen(np.poly(clustered))
-    assert rc == 0 and _hausdorff(r, clustered) < 2e-6   # three roots 1e-4 apart: sensitivity eps/sep^2 times the stopping level
+    # three roots 1e-4 apart: sensitivity eps/sep^2 ~ 2e-8 (numpy.roots, backward stable: 2.6e-8).  The sweeps' worst-case
+    # stopping bound leaves 1.7e-6; the two Newton steps that follow them (AberthParams::polish) reach the conditioning
+    assert rc == 0 and _hausdorff(r, clustered) < 1e-7
     double = np.array([0.25 + 0.1j, 0.25 + 0.1j, -1.0, 0.7j])
     rc, r = capi.poly_roots_fasteigen(np.poly(double))
-    assert rc in (0, -5)                               # a double root converges linearly: accepted or reported
-    assert _hausdorff(r, double) < 1e-6
+    assert rc == 0                                     # a double root: both estimates end inside its sqrt(eps) ball
+    assert _hausdorff(r, double) < 1e-7
 
 
 def test_scatter_bound_states_bo_golden(capi, oracle, fixtures):
