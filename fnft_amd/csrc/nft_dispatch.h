@@ -595,9 +595,12 @@ template <int DEG> struct KRPairSchool {
     static constexpr size_t lds_bytes() { return 0; }
     static FA_DEV void body(const Params &p) { body_rpair_school<DEG>(p); }
 };
+#ifndef FA_RPAIR_T
+#define FA_RPAIR_T 256   // lanes of a workgroup that holds several pairs (knob: 64 = one wave, barriers within the wave)
+#endif
 template <int M> struct RPairCfg {
     static constexpr int R = 4;
-    static constexpr int THREADS = (M / R > 256) ? M / R : 256;
+    static constexpr int THREADS = (M / R > FA_RPAIR_T) ? M / R : FA_RPAIR_T;
     static constexpr int B = THREADS / (M / R);
     static constexpr bool DB = true;
 };

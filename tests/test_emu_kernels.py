@@ -31,8 +31,8 @@ def _P(a):
 @pytest.fixture(scope="module")
 def emu():
     deps = [os.path.join(EMU_DIR, f) for f in ("emu_main.cpp", "emu_backend.h")]
-    deps += [os.path.join(CSRC, f) for f in ("dev_compat.h", "fft_dev.h", "nft_kernels.h", "nft_dispatch.h",
-                                             "nft_plan.h", "nft_api.h")]
+    deps += [os.path.join(CSRC, f) for f in ("dev_compat.h", "fft_dev.h", "nft_kernels.h", "nft_real.h", "nft_dispatch.h",
+                                             "nft_plan.h", "nft_api.h", "nft_discspec.h")]
     if not os.path.exists(EMU_LIB) or max(map(os.path.getmtime, deps)) > os.path.getmtime(EMU_LIB):
         subprocess.check_call(["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-pthread",
                                "-Wno-unknown-pragmas", "-o", EMU_LIB,
