@@ -37,6 +37,7 @@ groups["realbridge"] = ["KRBridge<%d>" % n for n in N1_BR + [1024]] + ["KMidGen<
 K3 = [1, 2, 4, 8, 16, 32, 64, 128, 256]
 groups["real3col"] = ["KR3ColFwd<%d>" % k for k in K3 + [512]] + ["KR3ColInv<%d>" % k for k in K3 + [512]]
 groups["real3bridge"] = ["KR3Bridge<%d>" % k for k in K3]
+groups["realleaf"] = ["KRLeafStrang<6, false>", "KRLeafStrang<6, true>", "KRLeafStrang<8, false>", "KRLeafStrang<8, true>"]
 groups["chirpa"] = ["KChirpRows"] + ["KChirpColFwd<%d, false>" % n for n in N1_CHIRP] + ["KChirpColFwd<%d, true>" % n for n in N1_CHIRP]
 groups["chirpb"] = (["KChirpColInv<%d, false, false>" % n for n in N1_CHIRP] + ["KChirpColInv<%d, true, false>" % n for n in N1_CHIRP]
                     + ["KChirpColInv<%d, false, true>" % n for n in N1_CHIRP])

@@ -816,3 +816,45 @@ template <class BE> bool dispatch_r3bridge(BE &be, const BigLevel &G)
     default: return false;
     }
 }
+#ifndef FA_RLEAF_DL
+#define FA_RLEAF_DL 96   // degree of the leaf matrices of the real even-order schemes (96: one more level without transforms)
+#endif
+template <int ORDER, bool BFIRST> constexpr int rleaf_dl()
+{   // 2SPLIT8A (degree 24): 48, the two rows of 97 coefficients plus a 100-entry step matrix do not fit the registers
+    return (RStrangCfg<ORDER, BFIRST>::DEG >= 24 && FA_RLEAF_DL > 48) ? 48 : FA_RLEAF_DL;
+}
+template <int ORDER, bool BFIRST> struct KRLeafStrang {
+    using Params = LeafParams;
+    static constexpr int DL = rleaf_dl<ORDER, BFIRST>();
+    static constexpr int THREADS = 128;
+    static constexpr int MIN_WAVES = 1;
+    static constexpr size_t lds_bytes()
+    {
+        constexpr size_t st = (size_t)THREADS * 2 * 16, us = (size_t)(THREADS / 2) * 8 * (RStrangCfg<ORDER, BFIRST>::DEG + 1);
+        return ((size_t)THREADS + (st > us ? st : us)) * sizeof(double);
+    }
+    static FA_DEV void body(const Params &p) { body_rleaf_strang<ORDER, BFIRST, DL, THREADS>(p); }
+};
+inline int rleaf_strang_samples(int akns_disc)
+{
+    switch (akns_disc) {
+    case 13: return rleaf_dl<6, false>() / RStrangCfg<6, false>::DEG;
+    case 14: return rleaf_dl<6, true>() / RStrangCfg<6, true>::DEG;
+    case 17: return rleaf_dl<8, false>() / RStrangCfg<8, false>::DEG;
+    case 18: return rleaf_dl<8, true>() / RStrangCfg<8, true>::DEG;
+    default: return 0;
+    }
+}
+template <class BE> bool dispatch_rleaf_strang(BE &be, const LeafParams &lp)
+{
+    const CoeffParams &p = lp.c;
+    const long long n = (long long)p.batch * (p.Dpad / lp.spt);
+    const int g = (int)((2 * n + 127) / 128);
+    switch (p.disc) {
+    case 13: be.template run<KRLeafStrang<6, false>>(g, 1, lp); return true;
+    case 14: be.template run<KRLeafStrang<6, true>>(g, 1, lp); return true;
+    case 17: be.template run<KRLeafStrang<8, false>>(g, 1, lp); return true;
+    case 18: be.template run<KRLeafStrang<8, true>>(g, 1, lp); return true;
+    default: return false;
+    }
+}

@@ -140,6 +140,7 @@ public:
     bool want_real = false;
     bool real_run = false;
     bool use_r3 = true;      // column lengths 3*2^j on the split levels of the real path
+    bool use_rleaf = true;   // real even-order schemes: leaf kernel with direct products (body_rleaf_strang)
     // 4SPLIT4A/B front end (set_front): Din input samples per signal, every nskip-th step kept,
     // ups preprocessed samples per kept step; D = ups * Dsub matrices enter the tree
     size_t Din = 0, nskip = 1;
@@ -464,8 +465,22 @@ public:
             if (!dispatch_leaf(be, lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
             return NFT_SUCCESS;
         }
+        const int rl_spt = (real_run && use_rleaf) ? rleaf_strang_samples(akns_disc) : 0;
+        if (rl_spt > 1 && Dpad >= (size_t)rl_spt) {
+            // even-order splitting schemes on the real path: coefficients from their elementary factors AND the ordered
+            // product of rl_spt consecutive samples by direct multiplication (body_rleaf_strang, nft_real.h)
+            ne = 4;
+            LeafParams lp;
+            lp.c = p;
+            lp.c.ne = 4;
+            lp.spt = rl_spt;
+            if (!dispatch_rleaf_strang(be, lp)) return NFT_EC_NOT_YET_IMPLEMENTED;
+            start_n = n0 / (size_t)rl_spt;
+            start_d = (size_t)deg0 * (size_t)rl_spt;
+            return NFT_SUCCESS;
+        }
         if (real_run && dispatch_rcoeffs_strang(be, p)) {
-            // even-order splitting schemes on the real path: composed from their elementary factors (nft_real.h)
+            // ... (short signals) coefficients only, composed from their elementary factors
             ne = 4;
         } else if (prog_ptr != nullptr) {
             // schemes of order 5..8: generated coefficient program; the symmetric form can start at

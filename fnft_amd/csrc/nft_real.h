@@ -527,17 +527,12 @@ template <int ORDER, bool BFIRST> struct RStrangCfg {
     static constexpr int T = ORDER / 2;
     static constexpr int DEG = (T == 3 ? 6 : 12) * (BFIRST ? 1 : 2);
 };
-template <int ORDER, bool BFIRST> FA_DEV void body_rcoeffs_strang(const CoeffParams &P)
+// coefficient matrix of slot j of signal b (sample D-1-j, or the identity pad z^deg * I of fnft__poly_fmult.c:422-438
+// beyond the signal; all zero for lanes outside the grid), highest power first
+template <int ORDER, bool BFIRST>
+FA_DEV void rstrang_sample(const CoeffParams &P, bool act, int b, long long j, double (&C)[4][RStrangCfg<ORDER, BFIRST>::DEG + 1])
 {
     constexpr int T = RStrangCfg<ORDER, BFIRST>::T, DEG = RStrangCfg<ORDER, BFIRST>::DEG;
-    FA_LDS_DECL
-    double *stage = (double *)FA_LDS_PTR;   // 64 x DEG
-    const int lane = FA_TID;
-    const long long gid0 = (long long)FA_BID * FA_BDIM, gid = gid0 + lane;
-    const long long n = (long long)P.batch * P.Dpad;
-    const bool act = gid < n;
-    const int b = act ? (int)(gid / P.Dpad) : 0, j = act ? (int)(gid % P.Dpad) : 0;
-    double C[4][DEG + 1];
 #pragma unroll
     for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -559,10 +554,24 @@ template <int ORDER, bool BFIRST> FA_DEV void body_rcoeffs_strang(const CoeffPar
             rstrang_term<DEG, 3, BFIRST>(P.eps_t, q, r, -729.0 / 280.0, C);
             rstrang_term<DEG, 4, BFIRST>(P.eps_t, q, r, 1024.0 / 315.0, C);
         }
-    } else if (act) {   // identity pad z^deg * I (fnft__poly_fmult.c:422-438)
+    } else if (act) {
         C[0][0] = 1.0;
         C[3][0] = 1.0;
     }
+}
+
+template <int ORDER, bool BFIRST> FA_DEV void body_rcoeffs_strang(const CoeffParams &P)
+{
+    constexpr int T = RStrangCfg<ORDER, BFIRST>::T, DEG = RStrangCfg<ORDER, BFIRST>::DEG;
+    FA_LDS_DECL
+    double *stage = (double *)FA_LDS_PTR;   // 64 x DEG
+    const int lane = FA_TID;
+    const long long gid0 = (long long)FA_BID * FA_BDIM, gid = gid0 + lane;
+    const long long n = (long long)P.batch * P.Dpad;
+    const bool act = gid < n;
+    const int b = act ? (int)(gid / P.Dpad) : 0, j = act ? (int)(gid % P.Dpad) : 0;
+    double C[4][DEG + 1];
+    rstrang_sample<ORDER, BFIRST>(P, act, b, j, C);
     const long long nact = (n - gid0 < 64) ? n - gid0 : 64;
     double *rb = (double *)P.body, *rt = (double *)P.tail;
 #pragma unroll
@@ -899,4 +908,152 @@ template <int K, int R, int BC> FA_DEV void body_r3bridge(const BigLevel &G)
     for (int t = 0; t < 3; t++)
 #pragma unroll
         for (int i = 0; i < 2 * R; i++) dst[yz_index(2 * N1, N2, v + (K / R) * i + 2 * K * t, n2)] = y[t][i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Leaf of the real path for the even-order schemes: the coefficient matrices of S = DL/DEG consecutive samples AND
+// their ordered product, by direct multiplication in registers -- levels 0 .. log2(S)-1 of the tree never touch HBM
+// and need no transforms (for fnft_kdvv's default 2SPLIT8B: three launches of 100 + 100 MB each).  A step matrix of
+// these schemes is sparse in z -- only the powers that are multiples of deg/n (B first) or deg/2n (A first) for some
+// n <= T occur, 7 of 13 for 2SPLIT8B -- so the running product acc <- acc * U costs (support size) multiply-adds per
+// coefficient and entry pair.  The rows of a 2x2 product are independent (new row r = old row r * U): two lanes per
+// leaf matrix, one per row, each with its row's two polynomials (2 x (DL+1) doubles) in registers; every index is a
+// compile-time constant after unrolling.  Rescaled like fnft__poly_fmult.c:330-374 (scale 1, exponent in wexp).
+// ---------------------------------------------------------------------------------------------
+template <int ORDER, bool BFIRST> constexpr bool rstrang_tap(int k)
+{
+    constexpr int T = RStrangCfg<ORDER, BFIRST>::T, DEG = RStrangCfg<ORDER, BFIRST>::DEG;
+    for (int n = 1; n <= T; n++) {
+        const int g = DEG / (BFIRST ? n : 2 * n);
+        if (k % g == 0) return true;
+    }
+    return false;
+}
+template <int ORDER, bool BFIRST, int DL, int SIDX> struct RLeafStep {
+    static constexpr int DEG = RStrangCfg<ORDER, BFIRST>::DEG;
+    // acc (degree DEG*SIDX, row r: a0 = entry (r,0), a1 = entry (r,1)) <- acc * U, in place, highest power first:
+    // new[k] = sum_t old[k-t] U[t]; descending k reads only indices that have not been overwritten
+    static FA_DEV void mul(double (&a0)[DL + 1], double (&a1)[DL + 1], const double (&U)[4][DEG + 1])
+    {
+        constexpr int dold = DEG * SIDX, dnew = dold + DEG;
+#pragma unroll
+        for (int k = dnew; k >= 0; k--) {
+            double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+            for (int t = 0; t <= DEG; t++) {
+                if (!rstrang_tap<ORDER, BFIRST>(t)) continue;
+                const int kk = k - t;
+                if (kk < 0 || kk > dold) continue;
+                n0 = fma(a0[kk], U[0][t], fma(a1[kk], U[2][t], n0));
+                n1 = fma(a0[kk], U[1][t], fma(a1[kk], U[3][t], n1));
+            }
+            a0[k] = n0;
+            a1[k] = n1;
+        }
+    }
+};
+// The two lanes of a leaf matrix share the step matrices: in round k the lane of row r forms U of sample 2k + r and
+// publishes it in LDS (ush: [matrix][2][4*(DEG+1)]), then both lanes multiply their row by the two matrices of the round.
+template <int ORDER, bool BFIRST, int DL, int K> struct RLeafLoop {
+    static constexpr int DEG = RStrangCfg<ORDER, BFIRST>::DEG, S = DL / DEG, W = 4 * (DEG + 1);
+    static FA_DEV void load_u(const double *src, double (&U)[4][DEG + 1])
+    {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int t = 0; t <= DEG; t++) U[e][t] = src[e * (DEG + 1) + t];
+    }
+    static FA_DEV void run(const CoeffParams &P, bool act, int b, long long j0, int row, double *ush_m, double (&a0)[DL + 1],
+                           double (&a1)[DL + 1])
+    {
+        if constexpr (2 * K < S) {
+            {
+                double U[4][DEG + 1];
+                rstrang_sample<ORDER, BFIRST>(P, act, b, j0 + 2 * K + row, U);
+                if (K > 0) FA_SYNC();   // the previous round's matrices have been read
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int t = 0; t <= DEG; t++) ush_m[row * W + e * (DEG + 1) + t] = U[e][t];
+            }
+            FA_SYNC();
+            double U[4][DEG + 1];
+            load_u(ush_m, U);
+            if constexpr (K == 0) {
+#pragma unroll
+                for (int k = 0; k <= DL; k++) {
+                    a0[k] = (k <= DEG) ? (row ? U[2][k <= DEG ? k : 0] : U[0][k <= DEG ? k : 0]) : 0.0;
+                    a1[k] = (k <= DEG) ? (row ? U[3][k <= DEG ? k : 0] : U[1][k <= DEG ? k : 0]) : 0.0;
+                }
+            } else {
+                RLeafStep<ORDER, BFIRST, DL, 2 * K>::mul(a0, a1, U);
+            }
+            load_u(ush_m + W, U);
+            RLeafStep<ORDER, BFIRST, DL, 2 * K + 1>::mul(a0, a1, U);
+            RLeafLoop<ORDER, BFIRST, DL, K + 1>::run(P, act, b, j0, row, ush_m, a0, a1);
+        }
+    }
+};
+// THREADS lanes = THREADS/2 leaf matrices per workgroup.  LDS: THREADS doubles (maxima) + THREADS * 2 * CH doubles (staging)
+template <int ORDER, bool BFIRST, int DL, int THREADS> FA_DEV void body_rleaf_strang(const LeafParams &LP)
+{
+    constexpr int DEG = RStrangCfg<ORDER, BFIRST>::DEG, S = DL / DEG, CH = 16;
+    static_assert(DL % DEG == 0 && DL % CH == 0 && S % 2 == 0, "leaf degree");
+    FA_LDS_DECL
+    double *mx = (double *)FA_LDS_PTR;        // THREADS
+    double *stage = mx + THREADS;             // [lane][2][CH]; the same space holds the shared step matrices before
+    double *ush = stage;                      // [matrix][2][4*(DEG+1)]
+    const CoeffParams &P = LP.c;
+    const int tid = FA_TID;
+    const long long per = P.Dpad / S;                    // leaf matrices per signal
+    const long long n_out = (long long)P.batch * per;
+    const long long g0 = (long long)FA_BID * (THREADS / 2);
+    const long long g = g0 + (tid >> 1);
+    const int row = tid & 1;
+    const bool act = g < n_out;
+    const int b = act ? (int)(g / per) : 0;
+    const long long j0 = act ? (g % per) * S : 0;
+    double a0[DL + 1], a1[DL + 1];
+    RLeafLoop<ORDER, BFIRST, DL, 0>::run(P, act, b, j0, row, ush + (size_t)(tid >> 1) * 8 * (DEG + 1), a0, a1);
+    FA_SYNC();   // the shared matrices have been read: their space becomes the staging area
+    // rescale: maximum over both rows (the two lanes of the matrix meet in LDS)
+    double m2 = 0.0;
+#pragma unroll
+    for (int k = 0; k <= DL; k++) m2 = fmax(m2, fmax(a0[k] * a0[k], a1[k] * a1[k]));
+    mx[tid] = m2;
+    FA_SYNC();
+    m2 = fmax(m2, mx[tid ^ 1]);
+    int a = 0;
+    double sc = 1.0;
+    if (m2 > 0.0 && m2 < 1.0e300) {
+        a = half_exponent(m2);
+        sc = pow2i(-a);
+    }
+    if (act && row == 0) {
+        P.scale[g] = 1.0;
+        P.wexp[g] = a;
+    }
+    double *rb = (double *)P.body, *rt = (double *)P.tail;
+    if (act) {
+        rt[(size_t)(2 * row) * n_out + g] = a0[DL] * sc;
+        rt[(size_t)(2 * row + 1) * n_out + g] = a1[DL] * sc;
+    }
+    const long long nvalid = (n_out - g0 < THREADS / 2) ? n_out - g0 : THREADS / 2;
+    // bodies leave through LDS, CH coefficients of every entry at a time, so that lanes write runs of CH doubles
+#pragma unroll
+    for (int c0 = 0; c0 < DL; c0 += CH) {
+        FA_SYNC();
+#pragma unroll
+        for (int kk = 0; kk < CH; kk++) {
+            stage[(size_t)tid * 2 * CH + kk] = a0[c0 + kk] * sc;
+            stage[(size_t)tid * 2 * CH + CH + kk] = a1[c0 + kk] * sc;
+        }
+        FA_SYNC();
+        const int total = (int)nvalid * 4 * CH;
+        for (int i = tid; i < total; i += THREADS) {
+            const int kk = i % CH, m = (i / CH) % (int)nvalid, e = i / (CH * (int)nvalid);
+            const int lane = 2 * m + (e >> 1);
+            rb[(size_t)e * P.plane + (size_t)(g0 + m) * DL + c0 + kk] = stage[(size_t)lane * 2 * CH + (e & 1) * CH + kk];
+        }
+    }
 }
