@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 N1_ALL = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]
-N1_CHIRP = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
+N1_CHIRP = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]
 N1_BR = [2, 4, 8, 16, 32, 64, 128, 256, 512]
 PF = [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 

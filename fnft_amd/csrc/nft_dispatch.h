@@ -266,7 +266,9 @@ template <int N1> struct ChirpColCfg {
 #ifndef FA_CHIRP_R_BIG
 #define FA_CHIRP_R_BIG 8
 #endif
-    static constexpr int R = (N1 <= 16) ? N1 : ((N1 >= 512) ? FA_CHIRP_R_BIG : 16);
+    // (8192: 16 points per lane, one column per 512-lane workgroup -- the any-length DFTs of the inverse transform at
+    // D = 2^20 and oversampling 8; slow, but there)
+    static constexpr int R = (N1 <= 16) ? N1 : ((N1 >= 8192) ? 16 : ((N1 >= 512) ? FA_CHIRP_R_BIG : 16));
     static constexpr int THREADS = (N1 <= 16) ? 256 : ((N1 <= 256) ? 256 : 512);
     static constexpr int BC = THREADS / (N1 / R);
     static constexpr bool DB = false;
@@ -524,7 +526,7 @@ template <class BE> bool dispatch_pair_fft(BE &be, const TreeLevel &L, int N)
 }
 
 #define FA_FOR_EACH_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
-#define FA_FOR_EACH_CHIRP_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096)
+#define FA_FOR_EACH_CHIRP_N1(X) X(2) X(4) X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
 
 template <class BE> bool dispatch_col_fwd(BE &be, const BigLevel &G)
 {

@@ -201,7 +201,7 @@ public:
     {
         const size_t L = dft_L(nmax);
         if (L > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
-        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, (size_t)1 << kFineLog2);
+        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, kTwLoEntries);
         ok = ok && pl.alloc(dY, L) && pl.alloc(dV, L) && pl.alloc(dstatus, 4);
         acc_cap = (nmax + 255) / 256;
         ok = ok && pl.alloc(dacc, acc_cap);

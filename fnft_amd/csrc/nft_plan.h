@@ -109,7 +109,9 @@ constexpr int kFineLog2 = 12;           // master twiddle: NMAX = 2^24
 constexpr int kMaxTwTable = 16384;      // per-length tables up to this length (longest column transform; the real path's
                                         // quarter-step tables of 4*N1 entries)
 constexpr size_t kMaxSplitTree = (size_t)kRowTree * 8192;    // largest column transform: 8192 (N up to 2^24)
-constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 4096;  // chirp length up to 2^24
+constexpr size_t kMaxSplitChirp = (size_t)kRowChirp * 8192;  // chirp length up to 2^25 (any-length DFTs up to 2^24 points)
+// fine tables of the two master twiddle pairs: 2^12 entries exp(-2 pi i j/2^24), then 2^13 entries exp(-2 pi i j/2^26)
+constexpr size_t kTwLoEntries = ((size_t)1 << kFineLog2) + ((size_t)1 << (kFineLog2 + 1));
 
 template <class BE> class NftPlan {
 public:
@@ -221,6 +223,13 @@ public:
     BigTwiddle big_tw(size_t N) const
     {
         BigTwiddle t;
+        if (N > ((size_t)1 << (2 * kFineLog2))) {   // 2^24 < N <= 2^26: the pair with 2^13-entry tables
+            t.hi = tw_table((size_t)1 << (kFineLog2 + 1));
+            t.lo = twlo + ((size_t)1 << kFineLog2);
+            t.fine_log2 = kFineLog2 + 1;
+            t.shift = 2 * (kFineLog2 + 1) - nft_log2(N);
+            return t;
+        }
         t.hi = tw_table((size_t)1 << kFineLog2);   // exp(-2 pi i jh / 2^FINE)
         t.lo = twlo;
         t.fine_log2 = kFineLog2;
@@ -269,7 +278,7 @@ public:
             ok = ok && alloc(chY, batch * 2 * Lc) && alloc(chV, Lc) && alloc(chVS, Lc);
         }
         ok = ok && alloc(tm_out, batch * 4 * (D * (size_t)deg0 + 1));
-        ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, (size_t)1 << kFineLog2);
+        ok = ok && alloc(twtab, (size_t)2 * kMaxTwTable) && alloc(twlo, kTwLoEntries);
         if (kdv) ok = ok && alloc(tw3tab, (size_t)3 << (kTw3MaxLog + 1)) && alloc(twlo3, (size_t)1 << kFineLog2);
         if (kdv) {
             ok = ok && alloc(rneg, batch * D);
@@ -327,11 +336,15 @@ public:
                     const long double a = -tau * (long double)j / (long double)N;
                     tw[N - 2 + j] = cmake((double)cosl(a), (double)sinl(a));
                 }
-            lo.resize((size_t)1 << kFineLog2);
+            lo.resize(kTwLoEntries);
             const long double nmax = (long double)((size_t)1 << (2 * kFineLog2));
-            for (size_t j = 0; j < lo.size(); j++) {
+            for (size_t j = 0; j < ((size_t)1 << kFineLog2); j++) {
                 const long double a = -tau * (long double)j / nmax;
                 lo[j] = cmake((double)cosl(a), (double)sinl(a));
+            }
+            for (size_t j = 0; j < ((size_t)1 << (kFineLog2 + 1)); j++) {
+                const long double a = -tau * (long double)j / (4.0L * nmax);
+                lo[((size_t)1 << kFineLog2) + j] = cmake((double)cosl(a), (double)sinl(a));
             }
             tw3.resize((size_t)3 << (kTw3MaxLog + 1));
             for (int b = 0; b <= kTw3MaxLog; b++) {
@@ -952,7 +965,7 @@ public:
         size_t L = nft_nextpow2(deg + 1 + Mo - 1);
         if (L < 2 * (size_t)kRowChirp) L = 2 * (size_t)kRowChirp;
         if (L > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
-        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, (size_t)1 << kFineLog2);
+        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, kTwLoEntries);
         cplx *dp = nullptr, *dY = nullptr, *dV = nullptr, *dH = nullptr;
         int *dstatus = nullptr;
         ok = ok && pl.alloc(dp, deg + 1) && pl.alloc(dY, L) && pl.alloc(dV, L) && pl.alloc(dH, Mo)
@@ -996,7 +1009,7 @@ public:
         size_t L = nft_nextpow2(2 * Dn - 1);
         if (L < 2 * (size_t)kRowChirp) L = 2 * (size_t)kRowChirp;
         if (L > kMaxSplitChirp) return NFT_EC_NOT_YET_IMPLEMENTED;
-        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, (size_t)1 << kFineLog2);
+        bool ok = pl.alloc(pl.twtab, (size_t)2 * kMaxTwTable) && pl.alloc(pl.twlo, kTwLoEntries);
         cplx *dq = nullptr, *dX = nullptr, *dX12 = nullptr, *dQ12 = nullptr, *dY = nullptr, *dV = nullptr;
         int *dstatus = nullptr;
         ok = ok && pl.alloc(dq, Dn) && pl.alloc(dX, Dn) && pl.alloc(dX12, 2 * Dn) && pl.alloc(dQ12, 2 * Dn)

@@ -218,7 +218,10 @@ FNFT_INT fnft_nsev_inverse_XI(const FNFT_UINT D, FNFT_REAL const *const T, const
  * M even and >= D, discretization 2SPLIT2A or 2SPLIT2_MODAL.  Argument checks in the reference's order with its return
  * codes.  On the GPU: the M-point and spectral-factorization DFTs (any length), the element-wise stages, the layer
  * peeling's products (fnft__nse_finvscatter), the multi-soliton recursion, the seed's eigenfunctions and the Darboux
- * steps.  Limit: DFT lengths up to 2^23 (spectral factorization at oversampling 8: D <= 2^19). */
+ * steps.  Limit: DFT lengths up to 2^24 (chirp transforms of 2^25 points), i.e. with the default oversampling factor 8
+ * of the spectral factorization (contspec_type B_OF_XI; B_OF_TAU and REFLECTION_COEFFICIENT factorize at degree D - 1
+ * resp. not at all) D <= 2^20; beyond it the call fails with FNFT_EC_NOT_YET_IMPLEMENTED wrapped as a subroutine
+ * failure.  fnft__nse_finvscatter itself: D * degree <= 2^24 as for the forward tree. */
 FNFT_INT fnft_nsev_inverse(const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI,
                            FNFT_UINT const K, FNFT_COMPLEX const *const bound_states,
                            FNFT_COMPLEX const *const normconsts_or_residues, const FNFT_UINT D, FNFT_COMPLEX *const q,

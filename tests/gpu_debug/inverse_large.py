@@ -14,7 +14,7 @@ for log2D in (19, 20):
     t0 = time.perf_counter()
     rc, q = capi.fnft_nsev_inverse(2 * D, cs[:2 * D].copy(), XI, None, None, D, T, 1, {"discretization": "2SPLIT2_MODAL"})
     print(log2D, "rc", rc, capi.last_error() if rc else "", "ms", (time.perf_counter() - t0) * 1e3, "err", S.rel_err(q, q0) if rc == 0 else None)
-    if log2D == 19:
+    if log2D >= 19:
         A, t00 = 0.45, 1.2
         XI2 = capi.nsev_inverse_XI(D, [-25.0, 25.0], D)[1]
         xi = XI2[0] + (XI2[1] - XI2[0]) / (D - 1) * np.arange(D)
@@ -22,4 +22,4 @@ for log2D in (19, 20):
             c2 = 1j * np.exp(-2j * xi * t00) * np.sin(np.pi * A) / np.cosh(np.pi * xi)
         t0 = time.perf_counter()
         rc, q = capi.fnft_nsev_inverse(D, c2, XI2, None, None, D, [-25.0, 25.0], 1, {"discretization": "2SPLIT2_MODAL", "contspec_type": "B_OF_XI"})
-        print("b_of_xi 2^19 rc", rc, "ms", (time.perf_counter() - t0) * 1e3, "err", S.rel_err(q, 1j * A / np.cosh(S.tgrid([-25.0, 25.0], D) - t00)) if rc == 0 else capi.last_error())
+        print("b_of_xi 2^%d rc" % log2D, rc, "ms", (time.perf_counter() - t0) * 1e3, "err", S.rel_err(q, 1j * A / np.cosh(S.tgrid([-25.0, 25.0], D) - t00)) if rc == 0 else capi.last_error())
