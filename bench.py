@@ -76,7 +76,7 @@ def launch_breakdown(plan, run_once, reps, B, D, deg0, sync=None):
             kind, lv = "leaf", 0
         elif base == "KMulti":
             kind, lv = "fused levels " + n, int(re.findall(r"\d+", n)[-1])
-        elif base in ("KPairSchool", "KPairFft", "KRPairSchool", "KRPair"):
+        elif base in ("KPairSchool", "KPairFft", "KRPairSchool", "KRPair", "KRPair4"):
             kind, lv = "single-launch levels", 1
         elif base in ("KMid", "KMidSym", "KMidGen"):
             kind, lv = "split levels", 1
@@ -229,6 +229,10 @@ def bench_cfg4(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+PEEL_CYCLES_PER_STEP = 272     # body_peel_leaf, wave 0, steady-state loop (see bench_inverse)
+PEEL_CLOCK_HZ = 2.4e9
+
+
 def bench_inverse(args, rank, world, local_rank):
     """fnft_nsev_inverse through the host-pointer drop-in: b(xi) of a sech pulse below the soliton
     threshold -> q (the reference's b_of_xi test at D = 2^log2D, default 2^16), 2SPLIT2_MODAL, M = D.  One call per step;
@@ -299,8 +303,18 @@ def bench_inverse(args, rank, world, local_rank):
             "config": {"workload": "fnft_nsev_inverse D=M=2^%d, contspec_type B_OF_XI (spectral factorization at "
                                    "oversampling 8 + layer peeling), 2SPLIT2_MODAL, host-pointer drop-in call, 1 spectrum per GPU"
                                    % log2D, "gather": "n/a"},
-            "roofline": {"bound": "hbm", "kernel": "layer peeling (leaf kernel + pair products); latency-bound chain, see DESIGN.md 5",
-                         "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+            # Layer peeling is a serial recursion: sample n cannot be formed before sample n+1 has been divided out.  The
+            # model is its floor on one wave: D steps of the leaf kernel's first-column chain, each 52 fp64 vector
+            # instructions (4 clocks each: 16 fp64 lanes per SIMD) + 16 cross-lane moves (v_readlane / DPP) = 272
+            # clocks at 2.4 GHz (counted in the ISA of body_peel_leaf's steady-state loop); the pair products above the
+            # leaves and the spectral factorization are on top of it, so frac = model / measured counts them as loss.
+            "roofline": {"bound": "latency", "kernel": "layer peeling (leaf kernel chain + pair products), DESIGN.md 5",
+                         "achieved": round(ms_per_step, 3), "peak": round(D * PEEL_CYCLES_PER_STEP / PEEL_CLOCK_HZ * 1e3, 3),
+                         "unit": "ms (peak = modelled floor of the serial chain)",
+                         "frac": round(D * PEEL_CYCLES_PER_STEP / PEEL_CLOCK_HZ * 1e3 / ms_per_step, 4), "traffic": None,
+                         "latency_model": {"serial_steps": D, "cycles_per_step": PEEL_CYCLES_PER_STEP,
+                                           "clock_GHz": PEEL_CLOCK_HZ / 1e9,
+                                           "model_ms": round(D * PEEL_CYCLES_PER_STEP / PEEL_CLOCK_HZ * 1e3, 3)},
                          "rel_err_vs_exact_signal": float(S.rel_err(q, exact))},
             "cpu_baseline": cpu,
         }

@@ -72,7 +72,19 @@ FA_DEV void fa_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 // a counter in LDS that one wave advances and other waves of the workgroup watch (body_peel_leaf): release store /
 // acquire load at workgroup scope, so what the writer stored before the counter is visible to who sees the counter
 FA_DEV void fa_lds_publish(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the same for a writer whose earlier LDS stores come from the SAME wave: a wave's LDS instructions are executed in
+// program order, so the counter cannot overtake them and the writer need not wait for them (the release store above
+// puts an s_waitcnt lgkmcnt(0) -- one LDS round trip -- in front of the counter); the compiler is kept from reordering
+FA_DEV void fa_lds_publish_inorder(int *p, int v)
+{
+    __asm__ volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __asm__ volatile("" ::: "memory");
+}
 FA_DEV int fa_lds_observe(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the instruction scheduler moves nothing across this point (hand-placed interleaving of a dependent chain with
+// independent work: a wave issues in order, so what follows a stalled instruction waits with it)
+FA_DEV void fa_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 FA_DEV void fa_nap() { __builtin_amdgcn_s_sleep(2); }   // ~128 clocks off the issue slots while polling
 // wave shuffles of doubles (body_peel_leaf: one wave per workgroup)
 FA_DEV double fa_shfl(double v, int src) { return __shfl(v, src, 64); }
@@ -176,6 +188,8 @@ FA_DEV double fa_rcp_approx(double x) { return 1.0 / x; }
 // the lane emulator runs no kernel that shuffles (body_peel_leaf is GPU-only): placeholders for the parser
 FA_DEV double fa_shfl(double v, int) { return v; }
 FA_DEV void fa_lds_publish(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+FA_DEV void fa_lds_publish_inorder(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+FA_DEV void fa_sched_fence() {}
 FA_DEV int fa_lds_observe(const int *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 FA_DEV void fa_nap() {}
 FA_DEV double fa_readlane(double v, int) { return v; }

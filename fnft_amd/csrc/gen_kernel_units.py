@@ -31,6 +31,7 @@ groups["mid"] = ["KMidSym<true>", "KMidSym<false>"]
 groups["col"] = ["KColFwd<%d>" % n for n in N1_ALL] + ["KColInv<%d>" % n for n in N1_ALL]
 groups["bridge"] = ["KColBridge<%d>" % n for n in N1_BR] + ["KColBridge2<%d>" % n for n in N1_BR + [1024, 2048, 4096]]
 groups["realpair"] = ["KRealCheck", "KRCoeffsStrang<6, false>", "KRCoeffsStrang<6, true>", "KRCoeffsStrang<8, false>", "KRCoeffsStrang<8, true>"] + ["KRPairSchool<%d>" % d for d in (1, 2, 3)] + ["KRPair<%d>" % m for m in (4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048)]
+groups["realpair4"] = ["KRPair4<%d>" % m for m in (32, 64, 128, 256, 512)]
 N1_RCOL = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 groups["realcol"] = ["KRColFwd<%d>" % n for n in N1_RCOL] + ["KRColInv<%d>" % n for n in N1_RCOL]
 groups["realbridge"] = ["KRBridge<%d>" % n for n in N1_BR + [1024]] + ["KMidGen<1024>", "KMidGen<2048>"]

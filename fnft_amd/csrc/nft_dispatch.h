@@ -618,6 +618,29 @@ template <int M> struct KRPair {
     }
     static FA_DEV void body(const Params &p) { body_rpair<M, C::R, C::B, C::DB>(p); }
 };
+// pair product with the four entries of a factor transformed at once (body_rpair4): M = 32 ... 512
+#ifndef FA_RPAIR4
+#define FA_RPAIR4 1
+#endif
+constexpr int kRPair4MinM = 32, kRPair4MaxM = 512;   // (1024 at 8 points per lane: 168 us against 133 for KRPair<1024>)
+template <int M> struct RPair4Cfg {
+    static constexpr int R = (M >= 1024) ? 8 : 4;
+    static constexpr int LANES = 4 * (M / R);                              // of one pair
+    static constexpr int THREADS = (LANES > 256) ? LANES : 256;
+    static constexpr int BP = THREADS / LANES;
+    static constexpr bool TWLDS = (M <= 512);
+};
+template <int M> struct KRPair4 {
+    using Params = TreeLevel;
+    using C = RPair4Cfg<M>;
+    static constexpr int THREADS = C::THREADS;
+    static constexpr int MIN_WAVES = 2;
+    static constexpr size_t lds_bytes()
+    {
+        return ((size_t)2 * M * 4 * C::BP + (C::TWLDS ? (size_t)M : 0)) * sizeof(cplx) + (size_t)((C::BP + 1) & ~1) * 8;
+    }
+    static FA_DEV void body(const Params &p) { body_rpair4<M, C::R, C::BP, C::TWLDS>(p); }
+};
 template <int N1> struct KRColFwd {
     using Params = BigLevel;
     using C = ColCfg<N1>;
@@ -664,6 +687,14 @@ template <class BE> bool dispatch_rpair_school(BE &be, const TreeLevel &L)
 template <class BE> bool dispatch_rpair(BE &be, const TreeLevel &L, int M)
 {
     const int pairs = L.n_in / 2;
+    if (FA_RPAIR4 && M >= kRPair4MinM && M <= kRPair4MaxM) {
+        switch (M) {
+#define X(m) case m: be.template run<KRPair4<m>>((pairs + RPair4Cfg<m>::BP - 1) / RPair4Cfg<m>::BP, 1, L); return true;
+            X(32) X(64) X(128) X(256) X(512)
+#undef X
+        default: break;
+        }
+    }
     switch (M) {
 #define X(m) case m: be.template run<KRPair<m>>((pairs + RPairCfg<m>::B - 1) / RPairCfg<m>::B, 1, L); return true;
         FA_FOR_EACH_RPAIR_M(X)
@@ -761,9 +792,20 @@ template <int K> struct R3Cfg {
     static constexpr size_t lds_col() { return (K > R) ? (size_t)K * BC * sizeof(cplx) : 0; }
     static constexpr size_t lds_bridge() { return (size_t)2 * K * BC * sizeof(cplx); }   // 2K points, 2R per lane: always > 2R? (K >= R)
 };
+// the long stand-alone column passes (first forward / last inverse pass of a tree) take more points per lane: fewer
+// lanes per column = more columns per workgroup = wider contiguous runs in memory (K = 512 at R = 4: 32-byte stores)
+#ifndef FA_R3COL_R_BIG
+#define FA_R3COL_R_BIG 8
+#endif
+template <int K> struct R3ColCfg {
+    static constexpr int R = (K >= 128) ? FA_R3COL_R_BIG : R3Cfg<K>::R;
+    static constexpr int THREADS = R3Cfg<K>::THREADS;
+    static constexpr int BC = THREADS / (K / R);
+    static constexpr size_t lds_col() { return (K > R) ? (size_t)K * BC * sizeof(cplx) : 0; }
+};
 template <int K> struct KR3ColFwd {
     using Params = BigLevel;
-    using C = R3Cfg<K>;
+    using C = R3ColCfg<K>;
     static constexpr int THREADS = C::THREADS;
     static constexpr int MIN_WAVES = 2;
     static constexpr size_t lds_bytes() { return C::lds_col(); }
@@ -771,7 +813,7 @@ template <int K> struct KR3ColFwd {
 };
 template <int K> struct KR3ColInv {
     using Params = BigLevel;
-    using C = R3Cfg<K>;
+    using C = R3ColCfg<K>;
     static constexpr int THREADS = C::THREADS;
     static constexpr int MIN_WAVES = 2;
     static constexpr size_t lds_bytes() { return C::lds_col(); }
@@ -792,7 +834,7 @@ template <class BE> bool dispatch_r3col_fwd(BE &be, const BigLevel &G)
 {
     const int polys = 4 * G.L.n_in;
     switch (G.N1 / 3) {
-#define X(k) case k: be.template run<KR3ColFwd<k>>(G.N2 / R3Cfg<k>::BC, polys, G); return true;
+#define X(k) case k: be.template run<KR3ColFwd<k>>(G.N2 / R3ColCfg<k>::BC, polys, G); return true;
         FA_FOR_EACH_R3_K(X) X(512)
 #undef X
     default: return false;
@@ -802,7 +844,7 @@ template <class BE> bool dispatch_r3col_inv(BE &be, const BigLevel &G)
 {
     const int polys = 4 * (G.L.n_in / 2);
     switch (G.N1 / 3) {
-#define X(k) case k: be.template run<KR3ColInv<k>>(G.N2 / R3Cfg<k>::BC, polys, G); return true;
+#define X(k) case k: be.template run<KR3ColInv<k>>(G.N2 / R3ColCfg<k>::BC, polys, G); return true;
         FA_FOR_EACH_R3_K(X) X(512)
 #undef X
     default: return false;

@@ -3180,6 +3180,11 @@ FA_DEV cplx fa_readlane_c(cplx v, int src) { return cmake(fa_readlane(v.x, src),
 FA_DEV cplx fa_shfl_up_c(cplx v) { return cmake(fa_shfl_up1(v.x), fa_shfl_up1(v.y)); }
 FA_DEV cplx fa_shfl_down_c(cplx v) { return cmake(fa_shfl_down1(v.x), fa_shfl_down1(v.y)); }
 FA_DEV cplx fa_shfl_down_cz(cplx v) { return cmake(fa_shfl_down1_z(v.x), fa_shfl_down1_z(v.y)); }
+// diagnostic builds (tests/gpu_debug/build_variant.py): 1 the inverse's waves skip their steps, 2 wave 0 skips its steps
+// (results are wrong in both; they time one side of the kernel alone)
+#ifndef FA_PEEL_DIAG
+#define FA_PEEL_DIAG 0
+#endif
 FA_DEV void body_peel_leaf(const PeelLeafParams &P)
 {
     constexpr int R = 4;
@@ -3203,46 +3208,99 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
             t2[s] = (K <= d) ? P.T[2 * P.Ts + K] : zero;
         }
         const int lastLane = (d - 1) / R, lastSlot = (d - 1) % R;
-        // one step; SLOT3: d is a multiple of 4, the constant terms sit in slot 3; FIRST: element 0 (t10, t20) is the
-        // left neighbour of lane 0 (only step 0 ever reads it)
-        auto step_fn = [&](int step, bool slot3, bool first) {
-            cplx c11 = t1[R - 1], c21 = t2[R - 1];          // constant terms T11[d], T21[d]
+        // Q = -kappa conj(c21 / c11) = -kappa c11 conj(c21) / |c11|^2 from the constant terms (reciprocal by v_rcp_f64 +
+        // two Newton steps); every lane forms the same value
+        auto q_of = [&](cplx c11, cplx c21) -> cplx {
+            return (c11 * cconj(c21)) * ((double)(-P.kappa) * aberth_rcp(cnorm2(c11)));
+        };
+        auto consts_of = [&](const cplx (&x1)[R], const cplx (&x2)[R], bool slot3, cplx &c11, cplx &c21) {
+            c11 = x1[R - 1]; c21 = x2[R - 1];                // constant terms T11[d], T21[d]
             if (!slot3) {
 #pragma unroll
                 for (int s = 0; s < R; s++)
-                    if (s == lastSlot) { c11 = t1[s]; c21 = t2[s]; }
+                    if (s == lastSlot) { c11 = x1[s]; c21 = x2[s]; }
             }
             c11 = fa_readlane_c(c11, lastLane);
             c21 = fa_readlane_c(c21, lastLane);
-            // Q = -kappa conj(c21 / c11) = -kappa c11 conj(c21) / |c11|^2 (reciprocal by v_rcp_f64 + two Newton steps:
-            // this division sits on the dependent chain of the block's d steps)
-            const cplx Q = (c11 * cconj(c21)) * ((double)(-P.kappa) * aberth_rcp(cnorm2(c11)));
+        };
+        // One step with its Q already known.  The dependent chain of the block runs Q_k -> constant terms of the
+        // updated arrays (one slot: two fused multiply-adds deep) -> v_readlane -> reciprocal -> Q_{k+1}; the other slots
+        // of step k are independent of it and fill its latencies: the step is written in that order (SLOT3: d is a
+        // multiple of 4, the constant terms sit in slot 3, which needs no neighbour lane; FIRST: element 0 (t10, t20) is
+        // the left neighbour of lane 0, only step 0 ever reads it).  Without the factor scl: Q only sees the ratio
+        // T21/T11, and the scale factors are multiplied onto the inverse at the end.
+        auto step_fn = [&](int step, cplx &Q, bool slot3, bool first) {
             if (lane == 0) {
                 Qs[step] = Q;
-                fa_lds_publish(ready, step + 1);            // the inverse's waves follow one step behind
+                fa_lds_publish_inorder(ready, step + 1);    // the inverse's waves follow behind
             }
-            const cplx kQc = cconj(Q) * (double)P.kappa;
-            // row 1 element-wise, row 2 takes the left neighbour (division by z); without the factor scl: Q only
-            // sees the ratio T21/T11, and the scale factors are multiplied onto the inverse at the end
-            cplx l1 = fa_shfl_up_c(t1[R - 1]), l2 = fa_shfl_up_c(t2[R - 1]);
-            if (first && lane == 0) { l1 = t10; l2 = t20; }
+            const cplx mQ = cmake(-Q.x, -Q.y), kQc = cconj(Q) * (double)P.kappa;
             cplx n1[R], n2[R];
+            if (slot3) {
+                // the chain, one link per line, each followed by one independent complex multiply-add of the other
+                // slots; the fences keep that order in the instruction stream
+                static_assert(R == 4, "step_fn: written for four coefficients per lane");
+                n1[3] = cfma(mQ, t2[3], t1[3]);
+                n2[3] = cfma(kQc, t1[2], t2[2]);
+                cplx l1 = fa_shfl_up_c(t1[R - 1]), l2 = fa_shfl_up_c(t2[R - 1]);
+                if (first && lane == 0) { l1 = t10; l2 = t20; }
+                fa_sched_fence();
+                const cplx c11 = fa_readlane_c(n1[3], lastLane), c21 = fa_readlane_c(n2[3], lastLane);
+                fa_sched_fence();
+                double m = c11.y * c11.y;                    n1[2] = cfma(mQ, t2[2], t1[2]);
+                fa_sched_fence();
+                m = fma(c11.x, c11.x, m);                    n2[2] = cfma(kQc, t1[1], t2[1]);
+                fa_sched_fence();
+                double r = fa_rcp_approx(m);                 n1[1] = cfma(mQ, t2[1], t1[1]);
+                fa_sched_fence();
+                double e = fma(-m, r, 1.0);                  n2[1] = cfma(kQc, t1[0], t2[0]);
+                fa_sched_fence();
+                r = fma(e, r, r);                            const cplx num = c11 * cconj(c21);
+                fa_sched_fence();
+                e = fma(-m, r, 1.0);                         n1[0] = cfma(mQ, t2[0], t1[0]);
+                fa_sched_fence();
+                r = fma(e, r, r);                            n2[0] = cfma(kQc, l1, l2);
+                fa_sched_fence();
+                Q = num * ((double)(-P.kappa) * r);          // garbage after the last step (never published)
+            } else {
+                // row 1 element-wise, row 2 takes the left neighbour (division by z)
 #pragma unroll
-            for (int s = 0; s < R; s++) {
-                n1[s] = t1[s] - Q * t2[s];
-                const cplx p1 = (s == 0) ? l1 : t1[s - 1], p2 = (s == 0) ? l2 : t2[s - 1];
-                n2[s] = kQc * p1 + p2;
+                for (int s = R - 1; s >= 1; s--) {
+                    n1[s] = cfma(mQ, t2[s], t1[s]);
+                    n2[s] = cfma(kQc, t1[s - 1], t2[s - 1]);
+                }
+                cplx l1 = fa_shfl_up_c(t1[R - 1]), l2 = fa_shfl_up_c(t2[R - 1]);
+                if (first && lane == 0) { l1 = t10; l2 = t20; }
+                n1[0] = cfma(mQ, t2[0], t1[0]);
+                n2[0] = cfma(kQc, l1, l2);
+                cplx c11, c21;
+                consts_of(n1, n2, false, c11, c21);
+                Q = q_of(c11, c21);
             }
 #pragma unroll
             for (int s = 0; s < R; s++) { t1[s] = n1[s]; t2[s] = n2[s]; }
         };
-        if (lastSlot == R - 1) {
-            step_fn(0, true, true);
-            for (int step = 1; step < d; step++) step_fn(step, true, false);
-        } else {
-            step_fn(0, false, true);
-            for (int step = 1; step < d; step++) step_fn(step, false, false);
+        {
+            cplx c11, c21;
+            consts_of(t1, t2, lastSlot == R - 1, c11, c21);
+            cplx Q = q_of(c11, c21);
+            if (FA_PEEL_DIAG == 2) {
+                if (lane == 0) fa_lds_publish_inorder(ready, d);
+            } else if (lastSlot == R - 1) {
+                // two steps per trip: the arrays change registers from step to step, the second step hands them back
+                step_fn(0, Q, true, true);
+                int step = 1;
+                for (; step + 1 < d; step += 2) {
+                    step_fn(step, Q, true, false);
+                    step_fn(step + 1, Q, true, false);
+                }
+                if (step < d) step_fn(step, Q, true, false);
+            } else {
+                step_fn(0, Q, false, true);
+                for (int step = 1; step < d; step++) step_fn(step, Q, false, false);
+            }
         }
+        // (lane 0's Qs are read by every lane of this wave below: LDS instructions of one wave execute in order)
         // samples and the product of the scale factors, all steps at once (off the dependent chain), :158-196
         double prod = 1.0;
         for (int step = lane; step < d; step += 64) {
@@ -3287,33 +3345,38 @@ FA_DEV void body_peel_leaf(const PeelLeafParams &P)
         }
         return have > upto;
     };
-    bool ok = want && wait_for(0);
-    cplx Qnext = ok ? Qs[0] : zero;
-    if (want && !ok && lane == 0) fa_atomic_or_i32(P.status, 32);
-    for (int step = 0; ok && step < d; step++) {
-        const cplx Q = Qnext;
-        if (step + 1 < d) {   // the next step's Q is fetched now, off the dependent chain of this step
-            if (!wait_for(step + 1)) { if (lane == 0) fa_atomic_or_i32(P.status, 32); break; }
-            Qnext = Qs[step + 1];
-        }
-        const cplx kQc = cconj(Q) * (double)P.kappa;
+    // four steps per visit of LDS: the counter is polled once and four Q are fetched at once, so the LDS round trips
+    // are off the per-step path (the waves run up to four steps behind wave 0, which never waits for them)
+    auto one_step = [&](cplx Q) {
+        const cplx mQ = cmake(-Q.x, -Q.y), kQc = cconj(Q) * (double)P.kappa;
         // row 1 takes the right neighbour (multiplication by z), row 2 element-wise
         const cplx r1 = fa_shfl_down_cz(a1[0]), r2 = fa_shfl_down_cz(a2[0]);   // zero behind the last lane
         // element 0 is kept by lane 0 alone (the other lanes' copies are never read): new element 0 from element 1,
         // which is lane 0's slot 0
-        const cplx n10 = a1[0] - Q * a2[0];
-        const cplx n20 = kQc * a10 + a20;
+        const cplx n10 = cfma(mQ, a2[0], a1[0]);
+        const cplx n20 = cfma(kQc, a10, a20);
         cplx m1[R], m2[R];
 #pragma unroll
         for (int s = 0; s < R; s++) {
             const cplx x1 = (s == R - 1) ? r1 : a1[s + 1], x2 = (s == R - 1) ? r2 : a2[s + 1];
-            m1[s] = x1 - Q * x2;
-            m2[s] = kQc * a1[s] + a2[s];
+            m1[s] = cfma(mQ, x2, x1);
+            m2[s] = cfma(kQc, a1[s], a2[s]);
         }
 #pragma unroll
         for (int s = 0; s < R; s++) { a1[s] = m1[s]; a2[s] = m2[s]; }
         a10 = n10;
         a20 = n20;
+    };
+    bool ok = want && FA_PEEL_DIAG != 1;
+    for (int step = 0; ok && step < d; step += 4) {
+        const int last = (step + 3 < d) ? step + 3 : d - 1;
+        if (!wait_for(last)) { if (lane == 0) fa_atomic_or_i32(P.status, 32); ok = false; break; }
+        cplx Qb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) Qb[u] = Qs[(step + u < d) ? step + u : d - 1];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (step + u < d) one_step(Qb[u]);
     }
     FA_SYNC();
     if (!want) return;

@@ -235,6 +235,116 @@ template <int M, int R, int B, bool DB> FA_DEV void body_rpair(const TreeLevel &
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same pair product with the FOUR entries of a factor transformed at once: a workgroup holds BP pairs, each by
+// four groups of M/R lanes (entry g = 2*row + col); batch index of the cooperative transform = 4*pair + entry.  Three
+// rounds of transforms (A, B, the product) instead of twelve -- a quarter of the barrier-separated exchange passes
+// of body_rpair -- and a third of the registers per lane (one entry of each factor instead of all of A and a column of
+// B).  Between the forward and the inverse round the spectra cross through LDS: every group needs row `row` of A and
+// column `col` of B at its own bins,  C[row][col] = A[row][0] B[0][col] + A[row][1] B[1][col].
+// LDS: two transform buffers of 4*BP*M elements (spectra exchange and the staged stores reuse them), the twiddle table
+// when small, BP maxima.
+// ---------------------------------------------------------------------------------------------
+// Measured (cfg 5, M = 128 / 256 / 512): 109 / 123 / 141 us against 138 / 132 / 144 of body_rpair; with the global loads
+// replaced by constants 83 / 101 / 119, without the stores 102 / 129 / 142, with the factors fetched by whole-workgroup
+// coalesced loads through LDS no change -- the kernel is bound by the instruction issue of its transform passes
+// (4 points per lane: ~1300 instructions per lane for 12 points), not by its memory accesses.
+template <int M, int R, int BP, bool TWLDS> FA_DEV void body_rpair4(const TreeLevel &L)
+{
+    constexpr int B4 = 4 * BP;                     // interleaved transforms
+    constexpr int T = B4 * (M / R);
+    constexpr size_t kBuf = (size_t)M * B4;        // one transform buffer
+    static_assert(M > R, "body_rpair4: at least one exchange pass");
+    FA_LDS_DECL
+    cplx *lds = (cplx *)FA_LDS_PTR;
+    cplx *twl = lds + 2 * kBuf;
+    unsigned long long *mx = (unsigned long long *)(twl + (TWLDS ? M : 0));
+    const int tid = FA_TID;
+    const int c = tid % B4, v = tid / B4;
+    const int g = c % 4, pl = c / 4;
+    const int row = g >> 1, col = g & 1;
+    if (tid < BP) mx[tid] = 0ull;
+    const cplx *tw = L.tw;
+    if (TWLDS) tw = stage_twiddles<M, T>(twl, L.tw);
+    RTreeIO<M, R, BP> io(L, pl, v);
+    cplx a[R], b[R];
+    io.load(0, g, a, v, pl);
+    io.load(1, g, b, v, pl);
+    int parity = 0;
+    fft_wg<M, R, B4, -1, true, !TWLDS>(a, lds, v, c, tw, parity);
+    fft_wg<M, R, B4, -1, true, !TWLDS>(b, lds, v, c, tw, parity);
+    // spectra of A into the idle buffer, of B into the other one (still being read by lanes that have not left the
+    // last exchange of B's transform: barrier first); element [pair][bin][entry]
+    cplx *SA = lds + (size_t)parity * kBuf, *SB = lds + (size_t)(parity ^ 1) * kBuf;
+#pragma unroll
+    for (int i = 0; i < R; i++) SA[((size_t)pl * M + (size_t)(v + (M / R) * i)) * 4 + g] = a[i];
+    FA_SYNC_LDS();
+#pragma unroll
+    for (int i = 0; i < R; i++) SB[((size_t)pl * M + (size_t)(v + (M / R) * i)) * 4 + g] = b[i];
+    FA_SYNC_LDS();
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const size_t o = ((size_t)pl * M + (size_t)(v + (M / R) * i)) * 4;
+        const cplx p = SA[o + 2 * row], q = SA[o + 2 * row + 1];
+        const cplx b1 = SB[o + col], b2 = SB[o + 2 + col];
+        a[i] = cfma(q, b2, p * b1);
+    }
+    FA_SYNC_LDS();   // the inverse transform writes into SA
+    fft_wg<M, R, B4, +1, true, !TWLDS>(a, lds, v, c, tw, parity);
+    // untwist, unfold (real part: coefficient idx, imaginary part: coefficient idx + M), alias fix, maximum; staged as
+    // doubles in the idle buffer, region [pair][entry] of 2d elements rotated by the batch index against bank conflicts
+    const int d2 = 2 * L.d;
+    const int n_out = L.n_in / 2;
+    const double inv = 1.0 / (double)M;
+    double *stage = (double *)(lds + (size_t)parity * kBuf);
+    double m2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int idx = v + (M / R) * i;
+        const cplx val = (a[i] * inv) * io.tws[i];
+        double re = val.x;
+        const double im = val.y;
+        if (io.active && idx == 0) {
+            const double tp = io.tail_product(g);
+            if (io.exact) re += tp;   // coefficient 2d = 2M came back on 0 with a minus sign
+            ((double *)L.tail_out)[(size_t)g * n_out + io.P] = tp;
+            m2 = fmax(m2, tp * tp);
+        }
+        const int hi = idx + M;
+        if (idx < d2) {
+            if (io.active) m2 = fmax(m2, re * re);
+            int rot = idx + c;
+            rot = rot >= d2 ? rot - d2 : rot;
+            stage[(size_t)c * d2 + rot] = re;
+        }
+        if (hi < d2) {
+            if (io.active) m2 = fmax(m2, im * im);
+            int rot = hi + c;
+            rot = rot >= d2 ? rot - d2 : rot;
+            stage[(size_t)c * d2 + rot] = im;
+        }
+    }
+    if (io.active) fa_atomic_max_u64(&mx[pl], dbits(m2));
+    FA_SYNC_LDS();
+    const long long P0 = (long long)FA_BID * BP;
+    const int total = B4 * d2;
+    for (int m = tid; m < total; m += T) {
+        const int c2 = m / d2, i2 = m - c2 * d2;
+        const long long Pq = P0 + c2 / 4;
+        if (Pq >= n_out) continue;
+        int rot = i2 + c2;
+        rot = rot >= d2 ? rot - d2 : rot;
+        ((double *)L.body_out)[(size_t)(c2 % 4) * L.plane + (size_t)Pq * d2 + i2] = stage[(size_t)c2 * d2 + rot];
+    }
+    if (v == 0 && g == 0 && io.active) {
+        const double mm = bitsd(mx[pl]);
+        int e2 = 0;
+        if (mm > 0.0 && mm < 1.0e300) e2 = half_exponent(mm);
+        L.scale_out[io.P] = pow2i(-e2);
+        L.wexp_out[io.P] = L.wexp_in[2 * io.P] + L.wexp_in[2 * io.P + 1] + e2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // split transforms, M = N1*N2 (element n = n1*N2 + n2, bin k = k1 + N1*k2).  The twist factors as
 // zeta^n = exp(2 pi i n1/(4 N1)) * exp(2 pi i n2/(4M)): the column kernels apply the first factor, the row kernel
 // (body_mid with BigLevel::rtwist) the second together with its own twiddle.  Y / Z scratch as in nft_kernels.h.

@@ -1,10 +1,13 @@
-"""One fnft_nsev_inverse call (b(xi) of a sech pulse, D = 2^LOG2D, default 18) for the profiler."""
+"""One fnft_nsev_inverse call (b(xi) of a sech pulse, D = 2^LOG2D, default 18) for the profiler.
+    python tests/gpu_debug/inverse_one.py [LOG2D [LIB]]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import signals as S
 from fnft_amd import capi
+if len(sys.argv) > 2:
+    capi.LIB_PATH = os.path.abspath(sys.argv[2])   # a diagnostic variant (build_variant.py)
 capi.load(); capi.silence_errors()
 D = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 18)
 T = [-25.0, 25.0]
