@@ -11,7 +11,10 @@
 #define FA_ROW_TREE 2048
 #endif
 constexpr int kRowTree = FA_ROW_TREE;      // N2 of the split transforms of the product tree
-constexpr int kRowChirp = 4096;     // N2 of the split transforms of the chirp z-transform
+#ifndef FA_ROW_CHIRP
+#define FA_ROW_CHIRP 4096
+#endif
+constexpr int kRowChirp = FA_ROW_CHIRP;     // N2 of the split transforms of the chirp z-transform
 constexpr int kFusedMaxN = 4096;    // largest pair product done by one workgroup
 constexpr int kSchoolMaxDeg = 3;    // direct products up to this input degree
 
