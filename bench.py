@@ -229,7 +229,7 @@ def bench_cfg4(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
-PEEL_CYCLES_PER_STEP = 272     # body_peel_leaf, wave 0, steady-state loop (see bench_inverse)
+PEEL_CYCLES_PER_STEP = 292     # body_peel_leaf, wave 0, steady-state loop (see bench_inverse)
 PEEL_CLOCK_HZ = 2.4e9
 
 
@@ -304,10 +304,11 @@ def bench_inverse(args, rank, world, local_rank):
                                    "oversampling 8 + layer peeling), 2SPLIT2_MODAL, host-pointer drop-in call, 1 spectrum per GPU"
                                    % log2D, "gather": "n/a"},
             # Layer peeling is a serial recursion: sample n cannot be formed before sample n+1 has been divided out.  The
-            # model is its floor on one wave: D steps of the leaf kernel's first-column chain, each 52 fp64 vector
-            # instructions (4 clocks each: 16 fp64 lanes per SIMD) + 16 cross-lane moves (v_readlane / DPP) = 272
-            # clocks at 2.4 GHz (counted in the ISA of body_peel_leaf's steady-state loop); the pair products above the
-            # leaves and the spectral factorization are on top of it, so frac = model / measured counts them as loss.
+            # model is its floor on one wave: D steps of the leaf kernel's first-column chain, each 49 fp64 vector
+            # instructions + 16 cross-lane moves (v_readlane / DPP) + 8 register moves = 73 vector instructions of 4
+            # clocks (16 lanes per SIMD) = 292 clocks at 2.4 GHz (counted in the ISA of body_peel_leaf's steady-state
+            # loop); the pair products above the leaves and the spectral factorization are on top of it, so frac =
+            # model / measured counts them as loss.
             "roofline": {"bound": "latency", "kernel": "layer peeling (leaf kernel chain + pair products), DESIGN.md 5",
                          "achieved": round(ms_per_step, 3), "peak": round(D * PEEL_CYCLES_PER_STEP / PEEL_CLOCK_HZ * 1e3, 3),
                          "unit": "ms (peak = modelled floor of the serial chain)",

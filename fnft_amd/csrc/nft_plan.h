@@ -237,6 +237,11 @@ public:
         return t;
     }
 
+    // largest pair product done by one workgroup.  General (4-entry) form: 2048 -- a 4096-point pair needs 8 + 4
+    // transforms of 16 points per lane in one workgroup (616 B of scratch per lane, 75 us for ONE pair); as a split
+    // transform of 4 columns x 1024-point rows it is three small launches (~30 us for one pair, rows over 4 CUs)
+    size_t fused_max_len() const { return (ne == 4 && FA_MID_GEN) ? (size_t)2048 : (size_t)kFusedMaxN; }
+
     int init()
     {
         if (D < 1 || batch < 1 || deg0 < 1) return NFT_EC_INVALID_ARGUMENT;
@@ -261,7 +266,7 @@ public:
             size_t needY = 0, needZ = 0, n = n0, d = (size_t)deg0;
             while (n / batch > 1) {
                 const size_t N = nft_product_len(d);
-                if (d > (size_t)kSchoolMaxDeg && N > (size_t)kFusedMaxN) {
+                if (d > (size_t)kSchoolMaxDeg && N > fused_max_len()) {
                     if (4 * n * N > needY) needY = 4 * n * N;
                     if (2 * n * N > needZ) needZ = 2 * n * N;
                 }
@@ -735,7 +740,7 @@ public:
             }
             if (d <= (size_t)kSchoolMaxDeg) {
                 ok = dispatch_pair_school(be, L);
-            } else if (N <= (size_t)kFusedMaxN) {
+            } else if (N <= fused_max_len()) {
                 ok = dispatch_pair_fft(be, L, (int)N);
             } else {
                 BigLevel G;

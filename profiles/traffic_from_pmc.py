@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     m = re.match(r"void kernel_entry<(.*)>\(", name)
-    return m.group(1).strip() if m else name[:40]
+    k = m.group(1).strip() if m else name[:40]
+    return re.sub(r"(, false)+>$", ">", k)   # bench.py's launch names leave trailing default arguments out
 
 
 def avg_counter(d, counter):
@@ -42,19 +43,22 @@ def main():
         line = json.loads(open(os.path.join(d, "p3.json")).read().strip().splitlines()[-1])
         wl = line["config"]["workload"]
         fetch, write = avg_counter(d, "FETCH_SIZE"), avg_counter(d, "WRITE_SIZE")
-        total, per_kernel = 0.0, {}
+        total, chirp, per_kernel = 0.0, 0.0, {}
         for st in line["roofline"]["stages"]:
             for k, cnt in st["launches"].items():
                 b = (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0
                 per_kernel[k] = {"launches": cnt, "fetch_MB": round(2 * fetch.get(k, 0.0) * 1024 / 1e6, 1),
                                  "write_MB": round(write.get(k, 0.0) * 1024 / 1e6, 1)}
-                total += b * cnt
+                if st.get("levels") is None and st["stage"].startswith("chirp"):
+                    chirp += b * cnt      # the evaluation stage is not part of roofline.traffic (the tree's launches)
+                else:
+                    total += b * cnt
         m = re.search(r"D=M=2\^(\d+).*?, (\w+), (\d+) signal", wl)
         wk = "cfg5" if "kdvv" in wl else ("cfg3" if int(m.group(3)) > 1 else "cfg2")
         key = "%s/D=2^%s/%s/B=%s" % (wk, m.group(1), m.group(2), m.group(3))
         table[key] = {"tree_hbm_bytes_per_step": int(total), "algorithmic_bytes": line["roofline"]["algorithmic_bytes"],
                       "tree_ms_under_profiler": line["roofline"]["tree_ms"], "per_kernel": per_kernel, "source": os.path.basename(d),
-                      "build_id": line.get("build_id")}
+                      "build_id": line.get("build_id"), "chirp_hbm_bytes_per_step": int(chirp)}
         print(key, "%.3f GB per step" % (total / 1e9))
     json.dump(table, open(path, "w"), indent=1)
 
