@@ -22,7 +22,8 @@ def main():
         print("| %s | %s | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
     if len(sys.argv) > 2:
         line = json.load(open(sys.argv[2]))
-        avg = {short(r["Name"]): (float(r["AverageNs"]) / 1e3) for r in rows}
+        # bench.py's launch names leave trailing default template arguments out
+        avg = {re.sub(r"(, false)+>$", ">", short(r["Name"])): (float(r["AverageNs"]) / 1e3) for r in rows}
         print()
         print("| stage (bench.py, HIP events) | levels | launches | us (events) | us (rocprof avg x launches) | "
               "algorithmic MB | GB/s | frac of 8 TB/s |")
