@@ -399,6 +399,11 @@ def main():
                          "D=M=2^20 through the drop-in fnft_nsev (host pointers, default options); cfg5: configs[4], "
                          "fnft_kdvv D=M=2^18 2SPLIT8B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ramp-steps", type=int, default=48,
+                    help="untimed steps before the timed region in total (warmup included): the clock ramp after an idle GPU")
+    ap.add_argument("--stage-events", type=int, default=1,
+                    help="record the plan's tree / chirp HIP events on every N-th step of the timed region (0: none there; "
+                         "the roofline pass after it always records them)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-transforms-in-flight rate")
     ap.add_argument("--gather", choices=("job", "step", "none"), default="step",
                     help="N>1: 'step' (default) = the result shards of EVERY step are gathered on rank 0 inside the "
@@ -500,6 +505,7 @@ def main():
 
     def one_step(i, pending, last=False):
         buf = outs[i % 2]
+        plan.set_timing(args.stage_events > 0 and (last or i % args.stage_events == 0))
         if gatherer is not None:
             gatherer.reserve()   # the gather that read this buffer two steps ago has finished
         rc = transform(buf.data_ptr())
@@ -520,6 +526,13 @@ def main():
     pending = []
     for i in range(args.warmup):
         one_step(i, pending, last=(i == args.warmup - 1))
+    # The GPU's clocks ramp over the first ~15 back-to-back transforms after an idle period (tests/gpu_debug/step_trend.py:
+    # 0.74 -> 0.70 ms per step), longer than the W warmup steps the command line asks for.  The timed region measures the
+    # transform, not the ramp: untimed steps follow the warmup until about 30 ms of back-to-back work have been queued
+    # (no result of theirs is used; `config.untimed_ramp_steps` says how many).
+    ramp_steps = max(0, args.ramp_steps - args.warmup)
+    for i in range(ramp_steps):
+        one_step(args.warmup + i, pending, last=(i == ramp_steps - 1))
     if gatherer is not None:
         gatherer.wait()
     pending = []
@@ -585,6 +598,7 @@ def main():
     if rank == 0:
         reps = max(5, args.steps)
         tms = []
+        plan.set_timing(True)
         for i in range(reps):
             transform(outs[0].data_ptr())
             torch.cuda.synchronize()
@@ -729,7 +743,7 @@ def main():
                                       "reflection" if cfg5 else "a,b + reflection", args.disc, B, "" if B == 1 else "s",
                                       " (configs[2]: 512 signals over 8 GPUs)" if cfg3 else ""),
                        "gather": (args.gather if world > 1 else "n/a (1 GPU)"),
-                       "event_ms_per_step": round(ev_ms / args.steps, 4)},
+                       "event_ms_per_step": round(ev_ms / args.steps, 4), "untimed_ramp_steps": ramp_steps},
             "roofline": roof, "cpu_baseline": cpu, "build_id": bid,
         }
         if multi:

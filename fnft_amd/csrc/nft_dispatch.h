@@ -426,7 +426,11 @@ template <class BE, int N> void run_pair_fft(BE &be, const TreeLevel &L)
 template <int N0, int STAGES> struct MultiCfg {
     static constexpr int R = 8;
     static constexpr int NF = N0 << (STAGES - 1);
-    static constexpr int THREADS = (NF >= 4096) ? 512 : 256;
+#ifndef FA_MULTI_T
+#define FA_MULTI_T 256   // lanes of a fused-level workgroup whose last stage is shorter than 4096 (knob: 64 = one wave, 128)
+#endif
+    static constexpr int TMIN = NF / R;                                   // one transform of the last stage
+    static constexpr int THREADS = (NF >= 4096) ? 512 : ((FA_MULTI_T > TMIN) ? FA_MULTI_T : TMIN);
     static constexpr int BF = THREADS * R / NF;
     static constexpr int P0 = BF << (STAGES - 1);
 #ifndef FA_MULTI_DB
