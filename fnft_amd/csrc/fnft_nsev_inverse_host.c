@@ -68,6 +68,19 @@ FNFT_INT fnft_nsev_inverse_XI(const FNFT_UINT D, FNFT_REAL const *const T, const
 }
 
 /* src/fnft_nsev_inverse.c:121-248 */
+/* contspec[i] *= prod_k (xi_i - lambda_k) / (xi_i - conj(lambda_k)): what the successful path does on the device
+ * (body_inv_op); only the validation failures of the reflection-coefficient branch need it on the host */
+static void blaschke_on_host(FNFT_UINT M, FNFT_COMPLEX *contspec, const FNFT_REAL *XI, FNFT_UINT K,
+                             const FNFT_COMPLEX *bound_states)
+{
+    if (K == 0 || contspec == NULL || XI == NULL || M < 2) return;
+    const FNFT_REAL step = (XI[1] - XI[0]) / (FNFT_REAL)(M - 1);
+    for (FNFT_UINT i = 0; i < M; i++) {
+        const FNFT_REAL xi = XI[0] + (FNFT_REAL)i * step;
+        for (FNFT_UINT k = 0; k < K; k++) contspec[i] *= (xi - bound_states[k]) / (xi - conj(bound_states[k]));
+    }
+}
+
 FNFT_INT fnft_nsev_inverse(const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI,
                            FNFT_UINT const K, FNFT_COMPLEX const *const bound_states,
                            FNFT_COMPLEX const *const normconsts_or_residues, const FNFT_UINT D, FNFT_COMPLEX *const q,
@@ -137,10 +150,21 @@ FNFT_INT fnft_nsev_inverse(const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT
                 break;
             case fnft_nsev_inverse_csmethod_TFMATRIX_CONTAINS_AB_FROM_ITER:
                 method = 2;
-                if (M != D) { ret_code = E_SUBROUTINE(E_INVALID_ARGUMENT(M)); goto leave_fun; }          /* :393-400 */
-                if (kappa != -1) { ret_code = E_SUBROUTINE(E_INVALID_ARGUMENT(kappa)); goto leave_fun; }
+                /* :393-400.  The reference has multiplied the Blaschke factors into the caller's contspec (:198-199,
+                 * :1013-1033) before these checks fail; a caller that inspects contspec afterwards sees the same here */
+                if (M != D) {
+                    blaschke_on_host(M, contspec, XI, K, bound_states);
+                    ret_code = E_SUBROUTINE(E_INVALID_ARGUMENT(M));
+                    goto leave_fun;
+                }
+                if (kappa != -1) {
+                    blaschke_on_host(M, contspec, XI, K, bound_states);
+                    ret_code = E_SUBROUTINE(E_INVALID_ARGUMENT(kappa));
+                    goto leave_fun;
+                }
                 break;
             default:
+                blaschke_on_host(M, contspec, XI, K, bound_states);
                 ret_code = E_SUBROUTINE(E_INVALID_ARGUMENT(opts_ptr->contspec_inversion_method));
                 goto leave_fun;
             }

@@ -684,19 +684,33 @@ FNFT_INT fnft__poly_fmult_two_polys2x2(const FNFT_UINT deg, FNFT_COMPLEX const *
 
 // include/private/fnft__nse_finvscatter.h (src/private/fnft__nse_finvscatter.c:234-366): samples from a transfer
 // matrix by layer peeling, every array on the device (NftLayerPeelingDev, nft_nsev_inverse.h)
+// argument errors of the private seams are raised like the reference raises them (E_INVALID_ARGUMENT(name): code + text
+// through the error hook, src/fnft_errwarn.c), not returned bare
+extern "C" FNFT_INT fnft_amd__raise(FNFT_INT ec, const char *func, int line, const char *msg);   // fnft_nsev_host.c
+static FNFT_INT seam_invalid(const char *func, int line, const char *arg)
+{
+    const std::string msg = std::string("Invalid argument ") + arg + ".";
+    return fnft_amd__raise(FNFT_EC_INVALID_ARGUMENT, func, line, msg.c_str());
+}
+#define SEAM_CHECK(cond, arg) do { if (cond) return seam_invalid(__func__, __LINE__, #arg); } while (0)
+
 FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer_matrix, FNFT_COMPLEX *const q,
                                const FNFT_REAL eps_t, const FNFT_INT kappa, const fnft_nse_discretization_t discretization)
 {
     // argument checks in the reference's order, :242-260
-    if (deg == 0 || !transfer_matrix || !q || !(eps_t > 0.0) || (kappa != -1 && kappa != 1)) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(deg == 0, deg);
+    SEAM_CHECK(!transfer_matrix, transfer_matrix);
+    SEAM_CHECK(!q, q);
+    SEAM_CHECK(!(eps_t > 0.0), eps_t);
+    SEAM_CHECK(kappa != -1 && kappa != 1, kappa);
     const int akns = nft_nse_to_akns((int)discretization);
     const int ddeg = akns < 0 ? 0 : nft_akns_degree(akns);
-    if (ddeg == 0) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(ddeg == 0, discretization);
     const size_t D = deg / (size_t)ddeg;
     if (D < 2 || (D & (D - 1)) != 0) return FNFT_EC_OTHER;           // not a power of two, :259-260
     // the base case exists for the two degree-1 schemes only, :164-211
     const bool modal = discretization == fnft_nse_discretization_2SPLIT2_MODAL;
-    if (!modal && discretization != fnft_nse_discretization_2SPLIT2A) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(!modal && discretization != fnft_nse_discretization_2SPLIT2A, discretization);
     if (current_device() < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(host_call_mutex());
     // one resident peeler per device: its pair-product plans (one per degree) and work arrays are reused by later
@@ -726,8 +740,11 @@ FNFT_INT fnft__nse_finvscatter(const FNFT_UINT deg, FNFT_COMPLEX *const transfer
 FNFT_INT fnft__poly_specfact(const FNFT_UINT deg, FNFT_COMPLEX const *const poly, FNFT_COMPLEX *const result,
                              const FNFT_UINT oversampling_factor, const FNFT_INT kappa)
 {
-    if (deg == 0 || !poly || !result || oversampling_factor == 0) return FNFT_EC_INVALID_ARGUMENT;   // :31-38
-    if (kappa != 0 && kappa != 1 && kappa != -1) return FNFT_EC_INVALID_ARGUMENT;                     // :105-107
+    SEAM_CHECK(deg == 0, deg);                                   // :31-38
+    SEAM_CHECK(!poly, poly);
+    SEAM_CHECK(!result, result);
+    SEAM_CHECK(oversampling_factor == 0, oversampling_factor);
+    SEAM_CHECK(kappa != 0 && kappa != 1 && kappa != -1, kappa);  // :105-107
     if (current_device() < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(host_call_mutex());
     HipBackend be;
@@ -804,7 +821,10 @@ extern "C" FNFT_INT fnft_amd__inverse_add_discrete(FNFT_UINT K, const FNFT_COMPL
 FNFT_INT fnft_amd_poly_chirpz(const FNFT_UINT deg, FNFT_COMPLEX const *const p, const double *A,
                               const double *W, const FNFT_UINT M, FNFT_COMPLEX *const result)
 {
-    if (!p || M == 0 || !result || !A || !W) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(!p, p);
+    SEAM_CHECK(M == 0, M);
+    SEAM_CHECK(!result, result);
+    SEAM_CHECK(!A || !W, A);
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
@@ -823,7 +843,10 @@ FNFT_INT fnft__misc_resample(const FNFT_UINT D, const FNFT_REAL eps_t, FNFT_COMP
                              const FNFT_REAL delta, FNFT_COMPLEX *const q_new)
 {
     // argument checks of the reference, :331-338
-    if (D <= 2 || !q || !q_new || eps_t == 0.0) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(D <= 2, D);
+    SEAM_CHECK(!q, q);
+    SEAM_CHECK(!q_new, q_new);
+    SEAM_CHECK(eps_t == 0.0, eps_t);
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(host_call_mutex());
@@ -838,7 +861,8 @@ FNFT_INT fnft__misc_resample(const FNFT_UINT D, const FNFT_REAL eps_t, FNFT_COMP
 // p[0] z^deg + ... + p[deg].  The reference calls eiscor's QR (Fortran); here the Ehrlich-Aberth kernels.
 FNFT_INT fnft__poly_roots_fasteigen(const FNFT_UINT deg, FNFT_COMPLEX const *const p, FNFT_COMPLEX *const roots)
 {
-    if (!p || !roots) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(!p, p);
+    SEAM_CHECK(!roots, roots);
     if (deg == 0) return FNFT_SUCCESS;
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
@@ -868,8 +892,14 @@ FNFT_INT fnft__nse_scatter_bound_states(const FNFT_UINT D, FNFT_COMPLEX const *c
 {
     (void)r;
     // argument checks in the reference's order, :53-66
-    if (D == 0 || !q || !T || K == 0 || !bound_states || !a_vals || !aprime_vals) return FNFT_EC_INVALID_ARGUMENT;
-    if (!skip_b_flag && !b) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(D == 0, D);
+    SEAM_CHECK(!q, q);
+    SEAM_CHECK(!T, eps_t);
+    SEAM_CHECK(K == 0, K);
+    SEAM_CHECK(!bound_states, bound_states);
+    SEAM_CHECK(!a_vals, a);
+    SEAM_CHECK(!aprime_vals, a_prime);
+    SEAM_CHECK(!skip_b_flag && !b, b);
     const bool cf42 = discretization == fnft_nse_discretization_CF4_2;
     if (discretization != fnft_nse_discretization_BO && !cf42) return FNFT_EC_NOT_YET_IMPLEMENTED;
     if (D < 2 || !(T[0] < T[1])) return FNFT_EC_INVALID_ARGUMENT;
@@ -962,9 +992,11 @@ FNFT_INT fnft__poly_roots_fftgridsearch(const FNFT_UINT deg, FNFT_COMPLEX const 
                                         FNFT_REAL const *const PHI, FNFT_COMPLEX *const roots)
 {
     // argument checks in the reference's order, :46-57
-    if (deg < 2 || !p || !M_ptr || *M_ptr < 2) return FNFT_EC_INVALID_ARGUMENT;
-    if (!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY) return FNFT_EC_INVALID_ARGUMENT;
-    if (!roots) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(deg < 2, deg);
+    SEAM_CHECK(!p, p);
+    SEAM_CHECK(!M_ptr || *M_ptr < 2, M_ptr);
+    SEAM_CHECK(!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY, PHI);
+    SEAM_CHECK(!roots, roots);
     if (current_device() < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(host_call_mutex());
     size_t M = *M_ptr;
@@ -976,9 +1008,11 @@ FNFT_INT fnft__poly_roots_fftgridsearch_paraherm(const FNFT_UINT deg, FNFT_COMPL
                                                  FNFT_REAL const *const PHI, FNFT_COMPLEX *const roots)
 {
     // :170-180: the degree must be even
-    if (deg % 2 == 1 || deg < 2 || !p || !M_ptr || *M_ptr < 2) return FNFT_EC_INVALID_ARGUMENT;
-    if (!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY) return FNFT_EC_INVALID_ARGUMENT;
-    if (!roots) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(deg % 2 == 1 || deg < 2, deg);
+    SEAM_CHECK(!p, p);
+    SEAM_CHECK(!M_ptr || *M_ptr < 2, M_ptr);
+    SEAM_CHECK(!PHI || !(PHI[0] < PHI[1]) || PHI[0] == -INFINITY || PHI[1] == INFINITY, PHI);
+    SEAM_CHECK(!roots, roots);
     if (current_device() < 0) return FNFT_EC_OTHER;
     std::lock_guard<std::mutex> host_lk(host_call_mutex());
     size_t M = *M_ptr;
@@ -1053,8 +1087,13 @@ FNFT_INT fnft__akns_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const q,
                              FNFT_INT *const W_ptr, fnft__akns_discretization_t discretization)
 {
     // argument checks in the reference's order, src/private/fnft__akns_fscatter.c:80-97
-    if (D == 0 || !q || !r || !(eps_t > 0.0) || !result || !deg_ptr) return FNFT_EC_INVALID_ARGUMENT;
-    if (nft_akns_degree((int)discretization) == 0) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(D == 0, D);
+    SEAM_CHECK(!q, q);
+    SEAM_CHECK(!r, r);
+    SEAM_CHECK(!(eps_t > 0.0), eps_t);
+    SEAM_CHECK(!result, result);
+    SEAM_CHECK(!deg_ptr, deg_ptr);
+    SEAM_CHECK(nft_akns_degree((int)discretization) == 0, discretization);
     const int dev = current_device();
     if (dev < 0) return FNFT_EC_OTHER;
     HipBackend be;
@@ -1104,7 +1143,11 @@ FNFT_INT fnft__kdv_fscatter(const FNFT_UINT D, FNFT_COMPLEX const *const u, cons
                             FNFT_COMPLEX *const result, FNFT_UINT *const deg_ptr, FNFT_INT *const W_ptr,
                             fnft_kdv_discretization_t discretization)
 {
-    if (D == 0 || !u || !(eps_t > 0.0) || !result || !deg_ptr) return FNFT_EC_INVALID_ARGUMENT;
+    SEAM_CHECK(D == 0, D);
+    SEAM_CHECK(!u, u);
+    SEAM_CHECK(!(eps_t > 0.0), eps_t);
+    SEAM_CHECK(!result, result);
+    SEAM_CHECK(!deg_ptr, deg_ptr);
     const int kd = kdv_alias((int)discretization);
     if (kd < 0 || kd > (int)fnft_kdv_discretization_2SPLIT8B) return FNFT_EC_INVALID_ARGUMENT;
     const int dev = current_device();

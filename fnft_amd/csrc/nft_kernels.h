@@ -2105,6 +2105,11 @@ struct ChirpParams {
     cplx *VS;
     int v_mode;
     int real_layout;     // body/tail are arrays of double (real-coefficient path, nft_real.h)
+    // != NULL: the tree's root has not been finalized (body_finalize_scales): the column kernel reduces the 64 maxima
+    // of its signal itself (scale = 2^-a instead of scale[b]) and one workgroup per signal stores scale and exponent
+    const unsigned *fin_max2;
+    double *fin_scale;
+    int *fin_wexp;
 };
 
 // exp((xr + i*xi)) with a real multiplier folded in: returns exp(t*lr) * cis(t*li)
@@ -2147,7 +2152,8 @@ template <bool DFT> FA_DEV cplx chirp_w(const ChirpParams &C, long long n, doubl
     return cpow_real(C.logW, half * dn * dn);
 }
 
-template <bool DFT> FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k)
+// sc: the signal's pending scale (C.scale[b], or formed by the caller from the unreduced maxima)
+template <bool DFT> FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int slot, long long k, double sc)
 {
     // coefficient k (highest power first) of polynomial `slot` of signal b
     if (DFT)
@@ -2156,13 +2162,15 @@ template <bool DFT> FA_DEV cplx chirp_poly_coef(const ChirpParams &C, int b, int
         return C.poly[((size_t)b * 4 + C.entry[slot]) * (size_t)(C.deg + 1) + (size_t)k];
     if (C.poly) return C.poly[((size_t)b * C.npoly + slot) * (size_t)(C.deg + 1) + (size_t)k];
     if (C.real_layout)
-        return stored_coef_real(C.body, C.tail, C.plane, C.deg_tot, C.batch, C.entry[slot], b, k) * C.scale[b];
-    return stored_coef(C.body, C.tail, C.plane, C.deg_tot, C.deg, C.batch, C.ne, C.entry[slot], b, k)
-           * C.scale[b];
+        return stored_coef_real(C.body, C.tail, C.plane, C.deg_tot, C.batch, C.entry[slot], b, k) * sc;
+    return stored_coef(C.body, C.tail, C.plane, C.deg_tot, C.deg, C.batch, C.ne, C.entry[slot], b, k) * sc;
 }
 
 // column step (forward) of the chirp-premultiplied polynomials and of the chirp filter
 //   grid.x = N2/BC, grid.y = batch*npoly + 1 (the last one is the filter v)
+// (Measured and dropped in round 3: one workgroup per signal that forms the chirp factor once for both polynomials --
+//  35 -> 39.5 us at cfg 2, half the workgroups; and a 30-instruction sincos for |x| < 2^17 in place of the library's --
+//  no change: the column kernels are not bound by their transcendentals.)
 template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_fwd(const ChirpParams &C)
 {
     FA_LDS_DECL
@@ -2174,6 +2182,22 @@ template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_f
     const int njobs = C.batch * C.npoly;
     const long long Lc = (long long)N1 * C.N2;
     const long long Np = C.deg + 1;
+    // pending scale of this job's signal: stored, or (root not finalized yet) from the 64 unreduced maxima -- every
+    // lane of every wave is active here; the first workgroup of the signal's first polynomial stores the result
+    double sc = 1.0;
+    if (job < njobs && !DFT && C.poly == nullptr) {
+        const int b = job / C.npoly;
+        if (C.fin_max2 != nullptr) {
+            const int a = exponent_of_max2(fa_slots_max_u32(C.fin_max2 + (size_t)b * kMax2Slots));
+            sc = pow2i(-a);
+            if (FA_BID == 0 && job % C.npoly == 0 && tid == 0) {
+                C.fin_scale[b] = sc;
+                C.fin_wexp[b] = C.fin_wexp[b] + a;
+            }
+        } else {
+            sc = C.scale[b];
+        }
+    }
     cplx x[R];
 #pragma unroll
     for (int i = 0; i < R; i++) {
@@ -2183,7 +2207,7 @@ template <int N1, int R, int BC, bool DB, bool DFT> FA_DEV void body_chirp_col_f
         const double dn = (double)n;
         if (job < njobs) {
             if (n < Np) {  // :68-69  p[deg-n] * A^-n * W^(n^2/2)
-                const cplx pc = chirp_poly_coef<DFT>(C, job / C.npoly, job % C.npoly, C.deg - n);
+                const cplx pc = chirp_poly_coef<DFT>(C, job / C.npoly, job % C.npoly, C.deg - n, sc);
                 val = DFT ? pc * chirp_w<true>(C, n, 0.5)
                           : pc * cpow_real2(C.logA, -dn, C.logW, 0.5 * dn * dn);
             }

@@ -164,6 +164,21 @@ public:
     size_t bytes = 0;
     int cur = 0;             // index of the body/tail/scale set holding the current level
     bool tree_valid = false;
+    // The last split level leaves its maxima unreduced (64 slots per matrix): turning them into the pending scale and
+    // the final exponent is a one-wave job (KFinalizeScales, 6 us as a launch of its own between the tree and the
+    // evaluation).  The chirp transform's first kernel does it on the way (every workgroup reduces the slots of its
+    // signal for itself, one of them stores scale and exponent: ChirpParams::fin_*); every other consumer of the root
+    // (export, discrete spectrum, block matrices) calls ensure_final() first.
+    bool final_pending = false;
+    TreeLevel final_L;
+    size_t final_n = 0;
+    void defer_final(const TreeLevel &L, size_t n_out) { final_L = L; final_n = n_out; final_pending = true; }
+    void ensure_final()
+    {
+        if (!final_pending) return;
+        be.template run<KFinalizeScales>((int)final_n, 1, final_L);
+        final_pending = false;
+    }
     size_t res_deg = 0;      // degree of the transfer matrix of the last tree run
     size_t start_n = 0, start_d = 0;  // matrices (all signals) / degree the tree run starts from
     bool use_leaf = true;    // fuse coefficients + first levels (nft_kernels.h body_leaf)
@@ -631,7 +646,7 @@ public:
                 zcur ^= 1;
                 y_from_bridge = ok && next_split;
                 const bool last_level = (n / 2 / batch <= 1);
-                if (ok && last_level) be.template run<KFinalizeScales>((int)(n / 2), 1, L);
+                if (ok && last_level) defer_final(L, n / 2);
                 in_pending = !last_level;
                 mcur ^= 1;
             } else if (M <= (size_t)kRealFusedMaxM) {
@@ -664,7 +679,7 @@ public:
                 zcur ^= 1;
                 y_from_bridge = ok && next_split;
                 const bool last_level = (n / 2 / batch <= 1);
-                if (ok && last_level) be.template run<KFinalizeScales>((int)(n / 2), 1, L);
+                if (ok && last_level) defer_final(L, n / 2);
                 in_pending = !last_level;
                 mcur ^= 1;
             }
@@ -680,6 +695,7 @@ public:
 
     int run_tree()
     {
+        final_pending = false;   // an unconsumed root of an earlier run is dropped
         if (real_run) return run_tree_real();
         size_t n = start_n;     // matrices at the current level, all signals
         size_t d = start_d;
@@ -782,7 +798,7 @@ public:
                 y_from_bridge = ok && next_split;
                 // the consumer of the next level finalizes this one; the last level needs a kernel
                 const bool last_level = (n / 2 / batch <= 1);
-                if (ok && last_level) be.template run<KFinalizeScales>((int)(n / 2), 1, L);   // one wave per matrix
+                if (ok && last_level) defer_final(L, n / 2);
                 in_pending = !last_level;
                 mcur ^= 1;
             }
@@ -800,6 +816,7 @@ public:
     // dst / stride / unscale: the result straight into a caller's strided device array, times 2^W (layer peeling)
     void export_tm(cplx *dst = nullptr, size_t stride = 0, bool unscale = false)
     {
+        ensure_final();
         ExportParams E;
         E.body = body[cur]; E.tail = tail[cur]; E.scale = scale[cur];
         E.out = dst ? dst : tm_out;
@@ -895,6 +912,7 @@ public:
                  + (shifted ? eps_t / deg1 : 0.0);
         C.cstype = cs.cstype;
         C.use_W = 1;  // W is the exponent actually taken out, whatever normalization_flag says
+        if (!from_tm) hand_final_to(C);
         return run_chirp_cached(C);
     }
 
@@ -935,7 +953,19 @@ public:
         C.pf_a = scheme_2A ? -eps_t / deg1 : 0.0;       // :186-195
         C.cstype = 10;
         C.real_layout = real_run ? 1 : 0;
+        hand_final_to(C);
         return run_chirp_cached(C);
+    }
+
+    // the root's pending finalize rides on the chirp transform's column kernel (one matrix per signal at the root)
+    void hand_final_to(ChirpParams &C)
+    {
+        if (!final_pending) return;
+        if (final_n != batch) { ensure_final(); return; }
+        C.fin_max2 = final_L.max2_out;
+        C.fin_scale = final_L.scale_out;
+        C.fin_wexp = final_L.wexp_out;
+        final_pending = false;
     }
 
     // the spectrum of the chirp filter only depends on W, M, the degree and the transform length:

@@ -221,7 +221,9 @@ FNFT_INT fnft_nsev_inverse_XI(const FNFT_UINT D, FNFT_REAL const *const T, const
  * steps.  Limit: DFT lengths up to 2^24 (chirp transforms of 2^25 points), i.e. with the default oversampling factor 8
  * of the spectral factorization (contspec_type B_OF_XI; B_OF_TAU and REFLECTION_COEFFICIENT factorize at degree D - 1
  * resp. not at all) D <= 2^20; beyond it the call fails with FNFT_EC_NOT_YET_IMPLEMENTED wrapped as a subroutine
- * failure.  fnft__nse_finvscatter itself: D * degree <= 2^24 as for the forward tree. */
+ * failure.  fnft__nse_finvscatter itself: D * degree <= 2^24 as for the forward tree.  A call that fails one of the
+ * checks of the reflection-coefficient branch (src/fnft_nsev_inverse.c:393-400, 512-556) leaves contspec multiplied by
+ * the Blaschke factors of the bound states, as the reference does (:198-199). */
 FNFT_INT fnft_nsev_inverse(const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT_REAL const *const XI,
                            FNFT_UINT const K, FNFT_COMPLEX const *const bound_states,
                            FNFT_COMPLEX const *const normconsts_or_residues, const FNFT_UINT D, FNFT_COMPLEX *const q,
@@ -230,6 +232,10 @@ FNFT_INT fnft_nsev_inverse(const FNFT_UINT M, FNFT_COMPLEX *const contspec, FNFT
 /* ======================================================================================== */
 /* 2. Private-layer seam (symbols the reference's libfnft.so also exports)                  */
 /* ======================================================================================== */
+/* Argument errors of fnft__akns_fscatter, fnft__kdv_fscatter, fnft__nse_finvscatter, fnft__poly_specfact,
+ * fnft__poly_chirpz (pointer twin), fnft__misc_resample, fnft__poly_roots_fasteigen, the grid searches and
+ * fnft__nse_scatter_bound_states are raised like the reference raises them: return code FNFT_EC_INVALID_ARGUMENT plus
+ * "Invalid argument <name>." through the fnft_errwarn_setprintf hook. */
 
 /* include/private/fnft__poly_fmult.h:199 -- 4*(deg+1)*nextpow2(n) */
 FNFT_UINT fnft__poly_fmult2x2_numel(const FNFT_UINT deg, const FNFT_UINT n);

@@ -145,10 +145,21 @@ def test_error_text_hook(capi):
     L.fnft_errwarn_setprintf(C.cast(cb, C.c_void_p))
     assert L.fnft_errwarn_getprintf() == C.cast(cb, C.c_void_p).value
     assert L.fnft_nsev(1, None, None, 0, None, None, None, None, None, 1, None) == 2
+    # the private seams raise their argument errors the same way (src/private/fnft__poly_roots_fasteigen.c:35-38,
+    # fnft__nse_finvscatter.c:250-259, fnft__poly_specfact.c:32-39: E_INVALID_ARGUMENT(name))
+    r4 = np.zeros(4, np.complex128)
+    assert L.fnft__poly_roots_fasteigen(C.c_size_t(3), None, r4.ctypes.data_as(C.c_void_p)) == 2
+    assert L.fnft__nse_finvscatter(C.c_size_t(8), r4.ctypes.data_as(C.c_void_p), r4.ctypes.data_as(C.c_void_p),
+                                   C.c_double(0.0), 1, 0) == 2
+    assert L.fnft__poly_specfact(C.c_size_t(4), r4.ctypes.data_as(C.c_void_p), r4.ctypes.data_as(C.c_void_p),
+                                 C.c_size_t(0), 1) == 2
     L.fnft_errwarn_setprintf(None)
     assert L.fnft_errwarn_getprintf() is None
     assert seen and seen[0][0].startswith(b"FNFT Error: %s") and b"Invalid argument D" in seen[0][1]
     assert seen[0][2] == b"fnft_nsev"
+    assert [(m, f) for _, m, f in seen[1:4]] == [(b"Invalid argument p.", b"fnft__poly_roots_fasteigen"),
+                                                 (b"Invalid argument eps_t.", b"fnft__nse_finvscatter"),
+                                                 (b"Invalid argument oversampling_factor.", b"fnft__poly_specfact")]
 
 
 def test_no_gpu_means_loud_failure(capi):
@@ -181,6 +192,36 @@ def test_kdvv_defaults_and_validation(capi):
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization="CF4_2")[0] == capi.FNFT_EC_NOT_YET_IMPLEMENTED
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1], discretization=99)[0] == -2
     assert capi.fnft_kdvv(u, [0, 1], 4, [-1, 1])[0] == capi.FNFT_EC_OTHER          # no GPU here
+
+
+def test_inverse_validation_failure_leaves_blaschke_factors_in_contspec(capi):
+    """src/fnft_nsev_inverse.c:198-199, 1013-1033: with REFLECTION_COEFFICIENT and bound states the reference has multiplied
+    the Blaschke factors into the CALLER'S contspec before transfer_matrix_from_reflection_coefficient's own checks
+    (:393-400: M != D, kappa != -1 for AB_FROM_ITER) fail; the drop-in leaves the same array behind (no GPU involved)."""
+    capi.silence_errors()
+    D, M = 16, 32                                                       # M must be even and >= D (:135-140)
+    XI = np.array([-2.0, 3.0])
+    xi = XI[0] + (XI[1] - XI[0]) / (M - 1) * np.arange(M)
+    cs0 = np.exp(-xi ** 2) * (1.0 + 0.5j)
+    bs = np.array([0.3 + 1.1j, -0.2 + 0.4j])
+    want = cs0.copy()
+    for lam in bs:
+        want = want * ((xi - lam) / (xi - np.conj(lam)))
+    opts = {"contspec_type": "REFLECTION_COEFFICIENT", "contspec_inversion_method": "TFMATRIX_CONTAINS_AB_FROM_ITER"}
+    cs = cs0.copy()
+    rc, _ = capi.fnft_nsev_inverse(M, cs, XI, bs, np.ones(2, np.complex128), D, [-1.0, 1.0], +1, opts)   # K > 0 needs kappa = +1
+    assert rc == -capi.FNFT_EC_INVALID_ARGUMENT                        # M != D, wrapped as a subroutine failure
+    assert np.allclose(cs, want, rtol=1e-15, atol=0)
+    cs = cs0[:D].copy()                                                 # M == D, kappa = +1
+    xiD = XI[0] + (XI[1] - XI[0]) / (D - 1) * np.arange(D)
+    wantD = cs.copy()
+    for lam in bs:
+        wantD = wantD * ((xiD - lam) / (xiD - np.conj(lam)))
+    rc, _ = capi.fnft_nsev_inverse(D, cs, XI, bs, np.ones(2, np.complex128), D, [-1.0, 1.0], +1, opts)
+    assert rc == -capi.FNFT_EC_INVALID_ARGUMENT and np.allclose(cs, wantD, rtol=1e-15, atol=0)
+    cs = cs0.copy()                                                     # no bound states: untouched
+    rc, _ = capi.fnft_nsev_inverse(M, cs, XI, None, None, D, [-1.0, 1.0], -1, opts)
+    assert rc == -capi.FNFT_EC_INVALID_ARGUMENT and np.array_equal(cs, cs0)
 
 
 def test_bench_launch_breakdown_assigns_every_level_once():
