@@ -1367,11 +1367,13 @@ struct BigLevel {
 
 // Element (row, n2) of one polynomial's Y/Z scratch block of `rows` x N2 elements.  The block is stored
 // in tiles of FA_YZ_TILE consecutive n2: [n2 tile][row][n2 in tile].  A column kernel that owns BC
-// consecutive n2 for every row then streams a contiguous region (rows x 1 KB per tile) instead of
-// touching `rows` places 16*N2 bytes apart, and a row kernel still moves whole 1 KB pieces per wave
-// instruction (64 consecutive n2).  FA_YZ_TILE = 0: plain [row][n2].
+// consecutive n2 for every row then streams a contiguous region (rows x 512 B per tile) instead of
+// touching `rows` places 16*N2 bytes apart, and a row kernel still moves whole 512 B pieces per half-wave
+// (a wave instruction covers 64 consecutive n2 = two tiles).  FA_YZ_TILE = 0: plain [row][n2].  Tile width measured
+// at cfg 2 (ms per step, three runs each): 128: 0.704, 64: 0.704-0.714, 32: 0.696-0.698, 16: 0.699, 8: 0.700 -- the
+// column kernels own 8 or 16 consecutive n2, so narrower tiles put more of a tile into one workgroup.
 #ifndef FA_YZ_TILE
-#define FA_YZ_TILE 64
+#define FA_YZ_TILE 32
 #endif
 FA_HD size_t yz_index(int rows, int N2, int row, int n2)
 {
