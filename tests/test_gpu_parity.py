@@ -1003,6 +1003,37 @@ def test_contspec_from_transfer_matrix_and_div_by_zero(capi, oracle):
         plan.close()
 
 
+def test_root_finalize_on_the_chirp_kernel_or_on_its_own(capi):
+    """The root of a tree that ends in split levels is finalized (64 maxima -> pending scale, exponent) either by the chirp
+    transform's first kernel (a transform with a spectrum) or by a launch of its own (a consumer that comes first: here the
+    export of the transfer matrix after a tree-only pass): both orders give the same matrices, exponents and spectra,
+    for every signal of a batch (src/private/fnft__poly_fmult.c:330-374,493: a and W of the last level)."""
+    import torch
+    D, M, B = 1 << 14, 256, 3
+    T, XI = [-25.0, 25.0], [-1.4, 1.6]
+    qh = np.stack([S.sech_focusing(D, amp=3.2 - 0.3 * b) for b in range(B)])
+    q = torch.from_numpy(qh).cuda()
+    for disc, deg0 in (("2SPLIT2_MODAL", 1), ("2SPLIT4B", 2)):
+        p1 = capi.Plan(D, M, batch=B, discretization=disc)
+        out = torch.zeros(B * 3 * M, dtype=torch.complex128, device="cuda")
+        assert p1.contspec_device(q.data_ptr(), out.data_ptr(), T, XI) == 0 and p1.finish() == 0
+        p2 = capi.Plan(D, M, batch=B, discretization=disc)
+        assert p2.contspec_device(q.data_ptr(), 0, T, XI) == 0 and p2.finish() == 0      # tree only
+        for b in range(B):
+            rc1, d1, tm1, W1 = p1.transfer_matrix(b)     # after the chirp kernel finalized the root
+            rc2, d2, tm2, W2 = p2.transfer_matrix(b)     # KFinalizeScales in front of the export
+            assert rc1 == 0 and rc2 == 0 and d1 == d2 == D * deg0 and W1 == W2 and W1 != 0
+            assert np.array_equal(tm1, tm2)
+            tmd = torch.from_numpy(tm2.reshape(-1)).cuda()
+            o2 = torch.zeros(3 * M, dtype=torch.complex128, device="cuda")
+            p3 = capi.Plan(D, M, batch=1, discretization=disc)
+            assert p3.contspec_from_tm_device(tmd.data_ptr(), W2, o2.data_ptr(), T, XI) == 0 and p3.finish() == 0
+            assert S.rel_err(o2.cpu().numpy(), out.cpu().numpy()[b * 3 * M:(b + 1) * 3 * M]) < 1e-13
+            p3.close()
+        p1.close()
+        p2.close()
+
+
 def test_discrete_spectrum_cfg4_normconsts_vs_oracle(capi, oracle, fixtures):
     """BASELINE.json configs[3] at full size: the norming constants and residues the GPU returns at D = 2^20 against
     the ORACLE's slow scatterer (BO, all 2^20 samples, sequential) evaluated at the GPU's own bound states:
