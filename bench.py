@@ -185,6 +185,18 @@ def bench_cfg4(args, rank, world, local_rank):
             tms.append(plan.last_ms(0))
         t_tree = float(np.median(tms[2:]))
         bt = bytes_tree(D, 2)
+        # counter traffic of the tree launches: the tree of this workload is the 2SPLIT4B tree of one 2^log2D signal --
+        # the launches profiles/tree_traffic.json holds under that key (same build only)
+        traffic4, bid4 = None, None
+        try:
+            from fnft_amd import build as fa_build
+            bid4 = fa_build.build_id()
+            with open(os.path.join(ROOT, "profiles", "tree_traffic.json")) as f:
+                ent4 = json.load(f).get("cfg2/D=2^%d/2SPLIT4B/B=1" % args.log2D) or {}
+            if ent4.get("build_id") == bid4:
+                traffic4 = ent4.get("tree_hbm_bytes_per_step")
+        except OSError:
+            pass
         # CPU baseline of THIS workload on a bounded sample: the oracle (contspec + bound states with the default
         # options: numpy root finder on the subsampled signal, sequential Newton refinement and norming constants)
         # on one D = M = 2^16 signal, 1 thread -- the full size would take minutes
@@ -215,14 +227,14 @@ def bench_cfg4(args, rank, world, local_rank):
                                    % args.log2D, "gather": "n/a"},
             "roofline": {"bound": "hbm", "kernel": "poly_fmult2x2 tree of the continuous-spectrum part (2SPLIT4B)",
                          "achieved": round(bt / (t_tree * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(bt / (t_tree * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                         "frac": round(bt / (t_tree * 1e-3) / 1e9 / 8000.0, 4), "traffic": traffic4,
                          "algorithmic_bytes": bt, "tree_ms": round(t_tree, 4),
                          "discspec_stages_ms": {k: round(v, 3) for k, v in stages.items()},
                          "bound_states": int(bs.size),
                          "bound_state_error": (float(max(np.abs(bs[:, None] - exact[None, :]).min(axis=0).max(),
                                                           np.abs(bs[:, None] - exact[None, :]).min(axis=1).max()))
                                                if bs.size else None)},
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "build_id": bid4,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -3774,6 +3774,8 @@ FA_DEV void body_aberth_apply(const AberthParams &P)
         const cplx zn = zk - corr;
         P.z_out[k] = zn;   // an estimate that stays writes its value into the other buffer too: both agree from now on
         moved = (corr.x != 0.0 || corr.y != 0.0);
+        // polish: only estimates that still moved by more than rounding take part in the second polish sweep
+        if (P.polish) moved = cnorm2(corr) > 1.0e-26 * (1.0 + az0) * (1.0 + az0);
         const double az = sqrt(cnorm2(zn));
         rel = sqrt(cnorm2(corr)) / (az > 1.0e-300 ? az : 1.0e-300);
     }
